@@ -1,0 +1,213 @@
+"""Pin the oracle (oracle/oracle.py + oracle/pghi_ref.c) against outputs of the
+reference itself (tests/golden/*.npz, made by tests/golden/make_golden.py).
+CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_max
+from oracle import oracle as O
+
+T = torch.from_numpy
+
+
+def test_windows_and_constants(golden):
+    g = golden("g1_constants")
+    for (n, h) in [(1024, 256), (512, 128), (128, 32), (32, 8), (2048, 512), (64, 16)]:
+        k = "%d_%d" % (n, h)
+        assert np.array_equal(O.hann_window(n).numpy(), g["hann_" + k])
+        gw = O.gauss_window(n)
+        assert np.array_equal(gw.numpy(), g["gauss_" + k])
+        assert np.allclose(O.dual_window(gw, n, h).numpy(), g["dual_" + k], rtol=2e-7, atol=0)
+        assert np.array_equal(O.gamma_offline(n).numpy(), g["gamma_dgt_" + k])
+        assert np.array_equal(O.gamma_offline(n).numpy(), g["gamma_stft_" + k])
+        assert np.array_equal(O.gamma_realtime(n).numpy(), g["gamma_rt_" + k])
+        assert float(O.oadd_gain(n, h)) == float(g["oadd_gain_" + k])
+    assert np.float32(O.EPS) == g["eps"]
+
+
+@pytest.mark.parametrize("name,n,h", [("stft", 1024, 256), ("stft", 128, 32), ("dgt", 1024, 256), ("dgt", 128, 32)])
+def test_stft_istft(golden, name, n, h):
+    g = golden("g2_stft")
+    x = T(g["x"])
+    if name == "stft":
+        w = O.hann_window(n)
+        iw = w
+    else:
+        w = O.gauss_window(n)
+        iw = O.dual_window(w, n, h)
+    k = "%s_%d_%d" % (name, n, h)
+    X = O.stft_forward(x, w, n, h)
+    assert np.array_equal(X.numpy(), g["X_" + k])
+    y = O.istft(X, iw, n, h)
+    assert rel_max(y.numpy(), g["y_" + k]) < 5e-7
+
+
+def test_stft_multidim_and_time(golden):
+    g = golden("g2_stft")
+    x = T(g["x_md"])
+    X = O.stft_forward(x, O.hann_window(1024), 1024, 256)
+    assert X.shape == g["X_md"].shape and np.array_equal(X.numpy(), g["X_md"])
+    assert np.array_equal(O.istft(X, O.hann_window(1024), 1024, 256).numpy(), g["y_md"])
+    tt = O.forward_with_time(17, 256, 44100, T(g["fwt_time_in"]))
+    assert np.array_equal(tt.numpy(), g["fwt_time_out"])
+
+
+def test_keep_input(golden):
+    g = golden("g2_stft")
+    X = T(g["X_stft_1024_256"])
+    y = O.polar_istft(X.abs(), T(g["phase_buffer_stft_1024_256"]), O.hann_window(1024), 1024, 256)
+    assert np.array_equal(y.numpy(), g["y_keep_input"])
+
+
+PGHI_CASES = ["n12x17", "t12x17", "s12x17", "n40x65", "t40x65", "d40x65", "s40x65", "n64x257", "d64x257",
+              "const6x17", "one1x17", "zero5x17"]
+
+
+@pytest.mark.parametrize("case", PGHI_CASES)
+def test_pghi_offline_exact_order(golden, case):
+    g = golden("g4_pghi_offline")
+    n_fft, hop, tol = g[case + "_params"]
+    r = O.pghi_offline(g[case + "_mag"], int(n_fft), int(hop), tol=np.float32(tol), want_order=True)
+    # (ii) pop order is bit exact (depends only on magnitude compares + heap tie-breaks)
+    assert np.array_equal(r["order"], g[case + "_order"])
+    # visited mask: phase exactly 0 where the reference left it at 0
+    assert np.array_equal(r["phase"] == 0, g[case + "_phase"] == 0)
+    # gradients: glibc logf vs torch's vectorised log differ by <= ~1 ulp of log|s|
+    assert np.allclose(r["tgradw"], g[case + "_tgradw"], rtol=0, atol=2e-5)
+    assert np.allclose(r["fgradw"], g[case + "_fgradw"], rtol=1e-5, atol=2e-4)
+    # (iii) phase within 1e-3 + 8 ulp(|phase_ref|)
+    ref = g[case + "_phase"]
+    tol_arr = 1e-3 + 8 * np.spacing(np.abs(ref).astype(np.float32)) + 2e-6 * np.abs(ref)
+    assert np.all(np.abs(r["phase"] - ref) <= tol_arr)
+
+
+def test_pghi_real_audio(golden):
+    g = golden("g10_agogo")
+    r = O.pghi_offline(g["mag_dgt"], 1024, 256)
+    ref = g["phase_pghi"]
+    assert np.array_equal(r["phase"] == 0, ref == 0)
+    tol_arr = 5e-3 + 16 * np.spacing(np.abs(ref).astype(np.float32)) + 1e-5 * np.abs(ref)
+    assert np.all(np.abs(r["phase"] - ref) <= tol_arr)
+
+
+@pytest.mark.parametrize("tag", ["k1", "k2", "k3"])
+def test_rtpghi_kernel(golden, tag):
+    g = golden("g5_rtpghi_kernel")
+    n, h = [int(v) for v in g[tag + "_params"]]
+    r = O.pghi_realtime(g[tag + "_magbuf"], g[tag + "_mag"], g[tag + "_phasebuf"], g[tag + "_noise"], n, h)
+    assert np.allclose(r["tgradw"], g[tag + "_tgradw"], rtol=1e-5, atol=3e-5)
+    assert np.allclose(r["fgradw"], g[tag + "_fgradw"], rtol=1e-5, atol=2e-3)
+    ref = g[tag + "_phase"]
+    tol_arr = 2e-3 + 16 * np.spacing(np.abs(ref).astype(np.float32)) + 1e-5 * np.abs(ref)
+    assert np.all(np.abs(r["phase"] - ref) <= tol_arr)
+
+
+@pytest.mark.parametrize("key", ["1024_256_4096", "1024_256_1024", "64_16_128"])
+def test_overlap_add_stream(golden, key):
+    g = golden("g6_overlap_add")
+    n, h, chunk = [int(v) for v in key.split("_")]
+    x = T(g["x_" + key])
+    fa, fi = O.OverlapAddState(n, h), O.OverlapAddState(n, h)
+    w = O.hann_window(n)
+    gw = O.gauss_window(n)
+    dw = O.dual_window(gw, n, h)
+    for c in range(3):
+        fr = fa.forward(x[:, c * chunk:(c + 1) * chunk])
+        X = O.rt_forward(fr, w)
+        yf = O.rt_invert(X, w)
+        y = fi.invert(yf)
+        assert np.array_equal(y.numpy(), g["y_%s_%d" % (key, c)])
+        assert np.array_equal(fi.outbuf.numpy(), g["outbuf_%s_%d" % (key, c)])
+        assert np.array_equal(fa.inbuf.numpy(), g["inbuf_%s_%d" % (key, c)])
+        if ("frames_%s_%d" % (key, c)) in g:
+            assert np.array_equal(fr.numpy(), g["frames_%s_%d" % (key, c)])
+            assert np.array_equal(X.numpy(), g["X_%s_%d" % (key, c)])
+            assert np.array_equal(yf.numpy(), g["yframes_%s_%d" % (key, c)])
+            Xd = O.rt_forward(fr, gw)
+            assert np.array_equal(Xd.numpy(), g["Xd_%s_%d" % (key, c)])
+            assert np.allclose(O.rt_invert(Xd, dw).numpy(), g["ydframes_%s_%d" % (key, c)], rtol=1e-6, atol=1e-7)
+
+
+def test_magnitude_all_modes(golden):
+    g = golden("g7_magnitude")
+    fwd, inv = O.magnitude_banks(T(g["bank"]))
+    assert np.array_equal(fwd.numpy(), g["mel_bank"])
+    assert np.array_equal(inv.numpy(), g["inverse_mel_bank"])
+    X = T(g["X"])
+    for c in ["log1p", "log", "log10", "none"]:
+        for mode in ["unipolar", "bipolar", "gaussian", "none"]:
+            for mel in [1, 0]:
+                k = "%s_%s_%d" % (c, mode, mel)
+                off = sc = None
+                if mode != "none":
+                    off, sc = O.magnitude_scale_stats(X, c, mode)
+                    assert np.array_equal(off.numpy(), g["offset_" + k])
+                    assert np.array_equal(sc.numpy(), g["scale_" + k])
+                y = O.magnitude_forward(X, fwd, c, off, sc, mel=bool(mel))
+                assert np.array_equal(y.numpy(), g["y_" + k]), k
+                xi = O.magnitude_invert(y, inv, c, off, sc, mel=bool(mel))
+                assert np.array_equal(xi.numpy(), g["inv_" + k]), k
+    assert np.array_equal(O.magnitude_forward(X[0], fwd, "log1p").numpy(), g["y_2d"])
+    assert np.array_equal(O.magnitude_forward(X[0, 0], fwd, "log1p").numpy(), g["y_1d"])
+    fwd, inv = O.magnitude_banks(T(g["bank513"]))
+    assert np.array_equal(fwd.numpy(), g["mel_bank513"])
+    X = T(g["X513"])
+    off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
+    y = O.magnitude_forward(X, fwd, "log1p", off, sc)
+    assert np.array_equal(y.numpy(), g["y513"])
+    assert np.array_equal(O.magnitude_invert(y, inv, "log1p", off, sc).numpy(), g["inv513"])
+
+
+def test_compose_stft_magnitude(golden):
+    g = golden("g7_compose")
+    x = T(g["x"])
+    fwd, inv = O.magnitude_banks(T(g["bank"]))
+    X = O.stft_forward(x, O.hann_window(1024), 1024, 256)
+    off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
+    assert np.array_equal(off.numpy(), g["offset"]) and np.array_equal(sc.numpy(), g["scale"])
+    y = O.magnitude_forward(X, fwd, "log1p", off, sc)
+    assert np.array_equal(y.numpy(), g["y"])
+    assert np.array_equal(O.magnitude_invert(y, inv, "log1p", off, sc).numpy(), g["mag_inv"])
+
+
+def test_normalize(golden):
+    g = golden("g9_normalize")
+    x = T(g["x"])
+    for mode in ["unipolar", "bipolar", "gaussian"]:
+        off, sc = O.normalize_stats(x, mode)
+        assert np.array_equal(off.numpy(), g["offset_" + mode])
+        assert np.array_equal(sc.numpy(), g["scale_" + mode])
+        y = (x - off) / sc
+        assert np.array_equal(y.numpy(), g["y_" + mode])
+        assert np.array_equal((y * sc + off).numpy(), g["inv_" + mode])
+
+
+def test_pghi_invert_end_to_end(golden):
+    g = golden("g4_pghi_invert")
+    mag = g["mag"]
+    gw = O.gauss_window(128)
+    dw = O.dual_window(gw, 128, 32)
+    ph = O.pghi_offline_batch(mag, 128, 32)
+    y = O.polar_istft(T(mag), T(ph), dw, 128, 32).numpy()
+    ref = g["y"]
+    # (iv) resynthesised audio compared by SNR vs the reference's own PGHI audio
+    snr = 10 * np.log10((ref ** 2).sum() / max(((y - ref) ** 2).sum(), 1e-30))
+    assert snr > 60.0, snr
+
+
+def test_unpinned_restatements_are_sane():
+    """torchaudio-backed pieces are parity-UNPINNED; check documented properties only."""
+    fb = O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100)
+    assert fb.shape == (513, 128) and float(fb.min()) >= 0 and float(fb.max()) <= 1.0
+    assert int(((fb > 0).sum(0) == 0).sum()) <= 1     # at most the first (narrowest) filter is empty
+    fb513 = O.magnitude_default_bank(44100, 1024)
+    assert fb513.shape == (513, 513)
+    assert int((fb513.sum(0) == 0).sum()) == 109 and int((fb513 != 0).sum()) == 1019
+    x = torch.linspace(-1, 1, 4001)
+    c = O.mulaw_encode(x)
+    assert c.dtype == torch.int64 and int(c.min()) == 0 and int(c.max()) == 255
+    assert float((O.mulaw_decode(c) - x).abs().max()) < 0.04
+    import scipy.fft
+    m = torch.rand(5, 128)
+    assert np.allclose(O.mfcc_dct(m, 40).numpy(), scipy.fft.dct(m.numpy(), type=2, norm="ortho")[:, :40], atol=1e-5)
