@@ -1,0 +1,101 @@
+"""ctypes binding of libacids_hip.so (the C ABI declared in include/acids_hip.h).
+
+There is no CPU fallback: if the library is missing, or a transform is handed
+a tensor that is not on a ROCm device, the call fails loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libacids_hip.so")
+
+c_f = ctypes.c_void_p      # device pointers travel as void*
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_flt = ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "at_abi_version": [],
+    "at_error_string": [c_int],
+    "at_init": [c_int],
+    "at_stft_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
+    "at_istft_envelope_table": [c_f, c_int, c_int, c_f, c_f],
+    "at_istft_workspace_bytes": [c_i64, c_i64, c_int, c_int],
+    "at_istft": [c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_sz, c_f],
+    "at_irfft_frames": [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f],
+    "at_angle": [c_f, c_i64, c_f, c_f],
+}
+_RESTYPES = {"at_error_string": ctypes.c_char_p, "at_istft_workspace_bytes": c_sz}
+
+
+class AcidsHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libacids_hip.so (in-tree)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_lib = None
+_inited = set()
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise AcidsHipError(
+                "libacids_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C acids_transforms_amd/csrc`. There is no CPU fallback." % _SO)
+        L = ctypes.CDLL(_SO)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the .so is stale: fail loudly
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AcidsHipError("%s failed: %s (%d)" % (what, lib().at_error_string(rc).decode(), rc))
+
+
+def require_device(*tensors):
+    """Product path guard: HIP kernels only, never a silent CPU route."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AcidsHipError(
+                "acids_transforms_amd runs on MI355X only: got a %s tensor. Move inputs (and the module, "
+                "`.to('cuda')`) to the ROCm device; there is no CPU fallback." % t.device)
+    dev = next(t for t in tensors if t is not None).device
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _inited:
+        with torch.cuda.device(idx):
+            check(lib().at_init(idx), "at_init")
+        _inited.add(idx)
+    return idx
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

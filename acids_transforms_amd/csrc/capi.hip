@@ -1,0 +1,170 @@
+// capi.hip -- extern "C" boundary of libacids_hip.so (see include/acids_hip.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/acids_hip.h"
+#include "fft512.h"
+
+namespace at_hip {
+// stft1024.hip
+int launch_stft1024_fwd(const float*, long long, long long, long long, long long, int, int, const float*,
+                        const float2*, float2*, float*, hipStream_t);
+int launch_istft1024_ola(const float2*, const float*, const float*, long long, long long, const float*, const float*,
+                         const float2*, float*, hipStream_t);
+int launch_irfft1024_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
+                            float*, hipStream_t);
+// stft_generic.hip
+int launch_rfft_generic(const float*, long long, long long, long long, long long, int, int, int, const float*,
+                        float2*, float*, hipStream_t);
+int launch_irfft_generic(const float2*, const float*, const float*, long long, int, const float*, float*,
+                         hipStream_t);
+int launch_ola_gather(const float*, long long, long long, int, int, const float*, float*, hipStream_t);
+
+constexpr int kMaxDevices = 16;
+static float2* g_twiddles[kMaxDevices] = {nullptr};
+
+static const float2* twiddles_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  return g_twiddles[dev];
+}
+
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+__global__ void envelope_table_kernel(const float* w, int n_fft, int hop, float* env16) {
+  // env16[mask][r] = sum over q in mask (ascending) of w[hop*(3-q) + r]^2; frames j-1+q, q = 0..3
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 16 * hop) return;
+  int mask = i / hop, r = i - mask * hop;
+  float s = 0.f;
+  for (int q = 0; q < 4; ++q)
+    if (mask & (1 << q)) {
+      int o = hop * (3 - q) + r;
+      if (o < n_fft) s += w[o] * w[o];
+    }
+  env16[i] = s;
+}
+}  // namespace at_hip
+
+using namespace at_hip;
+
+extern "C" {
+
+int at_abi_version(void) { return 1; }
+
+const char* at_error_string(int code) {
+  switch (code) {
+    case AT_OK: return "ok";
+    case AT_EINVAL: return "invalid argument";
+    case AT_EUNSUPPORTED: return "unsupported configuration";
+    case AT_ENOTINIT: return "at_init() not called for this device";
+    case AT_EWORKSPACE: return "workspace too small";
+    case AT_ELAUNCH: return "HIP launch/runtime error";
+    default: return "unknown error";
+  }
+}
+
+int at_init(int device) {
+  if (device < 0 || device >= kMaxDevices) return AT_EINVAL;
+  if (g_twiddles[device]) return AT_OK;
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess) return AT_ELAUNCH;
+  if (hipSetDevice(device) != hipSuccess) return AT_ELAUNCH;
+  std::vector<float2> tab(kTwiddleCount);
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int k = 1; k < 8; ++k)
+    for (int l = 0; l < 64; ++l) {
+      double a1 = -two_pi * (double)(l * k) / 512.0;
+      tab[(k - 1) * 64 + l] = make_float2((float)cos(a1), (float)sin(a1));
+      double a2 = -two_pi * (double)((l & 7) * k) / 64.0;
+      tab[(7 + k - 1) * 64 + l] = make_float2((float)cos(a2), (float)sin(a2));
+    }
+  for (int m = 0; m < 8; ++m)
+    for (int l = 0; l < 64; ++l) {
+      double a = -two_pi * (double)(l + 64 * m) / 1024.0;
+      tab[(14 + m) * 64 + l] = make_float2((float)cos(a), (float)sin(a));
+    }
+  float2* d = nullptr;
+  int rc = AT_OK;
+  if (hipMalloc((void**)&d, sizeof(float2) * kTwiddleCount) != hipSuccess) rc = AT_ELAUNCH;
+  if (rc == AT_OK && hipMemcpy(d, tab.data(), sizeof(float2) * kTwiddleCount, hipMemcpyHostToDevice) != hipSuccess)
+    rc = AT_ELAUNCH;
+  if (rc == AT_OK) g_twiddles[device] = d;
+  (void)hipSetDevice(prev);
+  return rc;
+}
+
+int at_stft_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
+                    int center, const float* window, float* out_complex, float* phase, void* stream) {
+  if (B < 0 || T < 0 || L < 0 || hop <= 0 || n_fft <= 0) return AT_EINVAL;
+  if (B * T == 0) return AT_OK;
+  if (!x || !window || !out_complex) return AT_EINVAL;
+  if (!is_pow2(n_fft) || n_fft < 8 || n_fft > 16384) return AT_EUNSUPPORTED;
+  if (center && L <= n_fft / 2) return AT_EINVAL;  // torch.stft: reflect pad must be < L
+  hipStream_t s = (hipStream_t)stream;
+  if (n_fft == 1024 && (((uintptr_t)window) & 7) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    if (!tw) return AT_ENOTINIT;
+    return launch_stft1024_fwd(x, B, L, clip_stride, T, hop, center, window, tw, (float2*)out_complex, phase, s);
+  }
+  return launch_rfft_generic(x, B, L, clip_stride, T, n_fft, hop, center, window, (float2*)out_complex, phase, s);
+}
+
+int at_istft_envelope_table(const float* inv_window, int n_fft, int hop, float* env16, void* stream) {
+  if (!inv_window || !env16 || hop <= 0 || n_fft <= 0) return AT_EINVAL;
+  int total = 16 * hop;
+  hipLaunchKernelGGL(envelope_table_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, inv_window,
+                     n_fft, hop, env16);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+static bool istft_fast(int n_fft, int hop, const float* env16, const float* w) {
+  return n_fft == 1024 && hop == 256 && env16 != nullptr && (((uintptr_t)w) & 7) == 0 &&
+         (((uintptr_t)env16) & 7) == 0;
+}
+
+size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop) {
+  if (n_fft == 1024 && hop == 256) return 0;
+  return (size_t)B * (size_t)T * (size_t)n_fft * sizeof(float);
+}
+
+int at_istft(const float* X_complex, const float* mag, const float* phase, int64_t B, int64_t T, int n_fft, int hop,
+             const float* inv_window, const float* env16, float* y, void* workspace, size_t workspace_bytes,
+             void* stream) {
+  if (B < 0 || T < 0 || hop <= 0 || n_fft <= 0) return AT_EINVAL;
+  if (B == 0 || T <= 1) return AT_OK;
+  if (!inv_window || !y) return AT_EINVAL;
+  if (!X_complex && !(mag && phase)) return AT_EINVAL;
+  if (!is_pow2(n_fft) || n_fft < 8 || n_fft > 16384) return AT_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (istft_fast(n_fft, hop, env16, inv_window) && (((uintptr_t)y) & 7) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    if (!tw) return AT_ENOTINIT;
+    return launch_istft1024_ola((const float2*)X_complex, mag, phase, B, T, inv_window, env16, tw, y, s);
+  }
+  size_t need = (size_t)B * (size_t)T * (size_t)n_fft * sizeof(float);
+  if (!workspace || workspace_bytes < need) return AT_EWORKSPACE;
+  int rc = launch_irfft_generic((const float2*)X_complex, mag, phase, B * T, n_fft, inv_window, (float*)workspace, s);
+  if (rc) return rc;
+  return launch_ola_gather((const float*)workspace, B, T, n_fft, hop, inv_window, y, s);
+}
+
+int at_irfft_frames(const float* X_complex, const float* mag, const float* phase, int64_t nframes, int n_fft,
+                    const float* inv_window, float* frames, void* stream) {
+  if (nframes < 0 || n_fft <= 0) return AT_EINVAL;
+  if (nframes == 0) return AT_OK;
+  if (!inv_window || !frames) return AT_EINVAL;
+  if (!X_complex && !(mag && phase)) return AT_EINVAL;
+  if (!is_pow2(n_fft) || n_fft < 8 || n_fft > 16384) return AT_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_fft == 1024 && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)frames) & 7) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    if (!tw) return AT_ENOTINIT;
+    return launch_irfft1024_frames((const float2*)X_complex, mag, phase, nframes, inv_window, tw, frames, s);
+  }
+  return launch_irfft_generic((const float2*)X_complex, mag, phase, nframes, n_fft, inv_window, frames, s);
+}
+
+}  // extern "C"

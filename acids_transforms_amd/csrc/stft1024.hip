@@ -1,0 +1,363 @@
+// stft1024.hip -- fused framing + window + rFFT-1024 (forward) and
+// irFFT-1024 + window + overlap-add (inverse) for gfx950.
+//
+// Replaces, for n_fft = 1024:
+//   torch.stft(...).transpose(-2,-1)        reference transforms/stft.py:98-104, dgt.py:64-70   (K1)
+//   x_fft.angle() phase buffer              stft.py:103, dgt.py:69                               (K2, optional)
+//   torch.istft(...)                        stft.py:120-128, dgt.py:86-93                        (K3)
+//   x * exp(1j*phase) before istft          stft.py:157-161, dgt.py:152-154                      (K15)
+//   torch.fft.rfft(x*window) / irfft(x)*w   stft.py:249-266, dgt.py:285-302 (pre-framed)         (K4/K5)
+//
+// Execution model: one 64-lane wavefront owns one frame at a time and keeps
+// window, twiddles (and, for the inverse, the overlap-add accumulators) in
+// registers across a run of frames.  No workgroup barrier anywhere; a
+// 256-thread block is just four independent waves sharing an LDS allocation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft512.h"
+
+namespace at_hip {
+
+constexpr int N = 1024;
+constexpr int F = 513;
+constexpr int WAVES_PER_BLOCK = 4;
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+struct FwdParams {
+  const float* x;       // audio, clip b at x + b*clip_stride
+  const float* window;  // N analysis window samples
+  const float2* tw;     // twiddle table (fft512.h)
+  float2* out;          // (B*T, 513) complex64
+  float* phase;         // (B*T, 513) or nullptr
+  long long B, L, clip_stride, T;
+  long long total_frames;     // B*T
+  long long frames_per_block; // multiple of WAVES_PER_BLOCK
+  int hop;
+  int center;  // 1: torch.stft center=True/reflect; 0: frame t starts at t*hop
+};
+
+__device__ __forceinline__ long long reflect_index(long long i, long long L) {
+  if (i < 0) i = -i;
+  if (i >= L) i = 2 * (L - 1) - i;
+  return i;
+}
+
+// loads z[lane + 64 m] = (x[2n], x[2n+1]) of frame (b, t) into v
+__device__ __forceinline__ void load_frame(const FwdParams& p, long long f, int lane, float2 (&v)[8]) {
+  const long long b = f / p.T;
+  const long long t = f - b * p.T;
+  const float* clip = p.x + b * p.clip_stride;
+  const long long start = t * (long long)p.hop - (p.center ? N / 2 : 0);
+  const bool interior = (start >= 0) && (start + N <= p.L);
+  const bool aligned = (((uintptr_t)(clip + start)) & 7) == 0;
+  if (interior && aligned) {
+    const float2* src = reinterpret_cast<const float2*>(clip + start);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = src[lane + 64 * m];
+  } else if (interior) {
+    const float* src = clip + start;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      v[m].x = src[2 * (lane + 64 * m)];
+      v[m].y = src[2 * (lane + 64 * m) + 1];
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      long long i0 = start + 2 * (lane + 64 * m);
+      if (p.center) {
+        v[m].x = clip[reflect_index(i0, p.L)];
+        v[m].y = clip[reflect_index(i0 + 1, p.L)];
+      } else {  // zero padding past the end (utils/misc.py:156 pad())
+        v[m].x = (i0 < p.L) ? clip[i0] : 0.0f;
+        v[m].y = (i0 + 1 < p.L) ? clip[i0 + 1] : 0.0f;
+      }
+    }
+  }
+}
+
+template <bool WRITE_PHASE>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stft1024_fwd_kernel(FwdParams p) {
+  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+
+  Twiddles tw;
+  load_twiddles<false>(tw, p.tw, lane);
+  float2 win[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) win[m] = reinterpret_cast<const float2*>(p.window)[lane + 64 * m];
+
+  const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
+  long long f_end = f_begin + p.frames_per_block;
+  if (f_end > p.total_frames) f_end = p.total_frames;
+
+  long long f = f_begin + wave;
+  float2 nxt[8];
+  if (f < f_end) load_frame(p, f, lane, nxt);
+  for (; f < f_end; f += WAVES_PER_BLOCK) {
+    float2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = make_float2(nxt[m].x * win[m].x, nxt[m].y * win[m].y);
+    // software prefetch of this wave's next frame
+    if (f + WAVES_PER_BLOCK < f_end) load_frame(p, f + WAVES_PER_BLOCK, lane, nxt);
+
+    fft512<false>(v, tw, lds, lane);
+    float2 nyq;
+    rfft_merge(v, tw, lane, nyq);
+
+    float2* row = p.out + f * F;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) row[lane + 64 * m] = v[m];
+    if (lane == 0) row[512] = nyq;
+    if (WRITE_PHASE) {
+      float* prow = p.phase + f * F;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) prow[lane + 64 * m] = atan2f(v[m].y, v[m].x);
+      if (lane == 0) prow[512] = atan2f(nyq.y, nyq.x);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// inverse
+// ---------------------------------------------------------------------------
+enum { IN_COMPLEX = 0, IN_POLAR = 1 };
+enum { OUT_OLA = 0, OUT_FRAMES = 1 };
+
+struct InvParams {
+  const float2* X;      // (B*T, 513) complex64           (IN_COMPLEX)
+  const float* mag;     // (B*T, 513)                      (IN_POLAR)
+  const float* phase;   // (B*T, 513)                      (IN_POLAR)
+  const float* window;  // N synthesis window samples
+  const float* env;     // OUT_OLA: 16 x hop table, env[mask][r] = sum of window^2 over the frames in mask
+  const float2* tw;
+  float* y;             // OUT_OLA: (B, hop*(T-1));  OUT_FRAMES: (B*T, 1024)
+  long long B, T;
+  long long runs_per_clip;  // OUT_OLA
+  long long slots_per_run;  // OUT_OLA
+  long long total_frames, frames_per_block;  // OUT_FRAMES
+};
+
+template <int IN_MODE>
+__device__ __forceinline__ void load_spectrum(const InvParams& p, long long f, int lane, float2 (&v)[8], float& nyq_re) {
+  if (IN_MODE == IN_COMPLEX) {
+    const float2* row = p.X + f * F;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = row[lane + 64 * m];
+    nyq_re = row[512].x;  // broadcast load; only lane 0 uses it
+  } else {
+    const float* mrow = p.mag + f * F;
+    const float* prow = p.phase + f * F;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      float a = mrow[lane + 64 * m];
+      float s, c;
+      sincosf(prow[lane + 64 * m], &s, &c);
+      v[m] = make_float2(a * c, a * s);
+    }
+    float s, c;
+    sincosf(prow[512], &s, &c);
+    nyq_re = mrow[512] * c;
+  }
+}
+
+// one frame: spectrum -> windowed time samples y[m] = (x[2n], x[2n+1]) * w, n = lane + 64 m
+__device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const Twiddles& tw, const float2 (&win)[8],
+                                            float2* lds, int lane) {
+  irfft_split(v, tw, lane, nyq_re);
+  fft512<true>(v, tw, lds, lane);
+  const float s = 1.0f / 1024.0f;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = make_float2((v[m].x * s) * win[m].x, (v[m].y * s) * win[m].y);
+}
+
+// K3: irFFT + window + overlap-add (hop = 256 = N/4) + envelope division + centre trim.
+// A wave produces output hop-slots [j0, j1) of one clip, streaming over frames
+// j0-1 .. j1+1 with the four overlapping frames' partial sums in registers.
+template <int IN_MODE>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void istft1024_ola_kernel(InvParams p) {
+  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+
+  const long long run = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
+  const long long b = run / p.runs_per_clip;
+  if (b >= p.B) return;
+  const long long r = run - b * p.runs_per_clip;
+  const long long nslots = p.T - 1;
+  const long long j0 = r * p.slots_per_run;
+  long long j1 = j0 + p.slots_per_run;
+  if (j1 > nslots) j1 = nslots;
+  if (j0 >= j1) return;
+
+  Twiddles tw;
+  load_twiddles<true>(tw, p.tw, lane);
+  float2 win[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) win[m] = reinterpret_cast<const float2*>(p.window)[lane + 64 * m];
+
+  float2 acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
+
+  const long long fbase = b * p.T;
+  float* yclip = p.y + b * (256 * nslots);
+  long long t = (j0 > 0) ? j0 - 1 : 0;
+  const long long t_last = j1 + 1;  // inclusive; frames >= T contribute nothing
+
+  float2 nxt[8];
+  float nxt_nyq = 0.f;
+  if (t < p.T) load_spectrum<IN_MODE>(p, fbase + t, lane, nxt, nxt_nyq);
+  // accumulators start aligned with frame t: acc[m] covers padded samples t*256 + 2*(lane+64m)
+  for (; t <= t_last; ++t) {
+    if (t < p.T) {
+      float2 v[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = nxt[m];
+      float nyq = nxt_nyq;
+      if (t + 1 <= t_last && t + 1 < p.T) load_spectrum<IN_MODE>(p, fbase + t + 1, lane, nxt, nxt_nyq);
+      synth_frame(v, nyq, tw, win, lds, lane);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[m] = cadd(acc[m], v[m]);
+    }
+    const long long j = t - 2;  // padded slot t is complete -> output slot j
+    if (j >= j0 && j < j1) {
+      // frames contributing to output slot j are j-1 .. j+2
+      int mask = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        long long tt = j - 1 + q;
+        if (tt >= 0 && tt < p.T) mask |= 1 << q;
+      }
+      const float2* env = reinterpret_cast<const float2*>(p.env + mask * 256);
+      float2* dst = reinterpret_cast<float2*>(yclip + j * 256);
+      float2 e0 = env[lane], e1 = env[lane + 64];
+      dst[lane] = make_float2(acc[0].x / e0.x, acc[0].y / e0.y);
+      dst[lane + 64] = make_float2(acc[1].x / e1.x, acc[1].y / e1.y);
+    }
+    // advance the accumulator window by one hop (= 2 register slots)
+#pragma unroll
+    for (int m = 0; m < 6; ++m) acc[m] = acc[m + 2];
+    acc[6] = make_float2(0.f, 0.f);
+    acc[7] = make_float2(0.f, 0.f);
+  }
+}
+
+// K5: irFFT + window, frames out (no overlap-add): RealtimeSTFT/RealtimeDGT.invert
+template <int IN_MODE>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void irfft1024_frames_kernel(InvParams p) {
+  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  Twiddles tw;
+  load_twiddles<true>(tw, p.tw, lane);
+  float2 win[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) win[m] = reinterpret_cast<const float2*>(p.window)[lane + 64 * m];
+  const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
+  long long f_end = f_begin + p.frames_per_block;
+  if (f_end > p.total_frames) f_end = p.total_frames;
+  for (long long f = f_begin + wave; f < f_end; f += WAVES_PER_BLOCK) {
+    float2 v[8];
+    float nyq;
+    load_spectrum<IN_MODE>(p, f, lane, v, nyq);
+    synth_frame(v, nyq, tw, win, lds, lane);
+    float2* dst = reinterpret_cast<float2*>(p.y + f * N);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) dst[lane + 64 * m] = v[m];
+  }
+}
+
+}  // namespace at_hip
+
+// ---------------------------------------------------------------------------
+// host launchers (C++ linkage inside the library; the extern "C" ABI is capi.hip)
+// ---------------------------------------------------------------------------
+namespace at_hip {
+
+static inline int num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+int launch_stft1024_fwd(const float* x, long long B, long long L, long long clip_stride, long long T, int hop,
+                        int center, const float* window, const float2* tw, float2* out, float* phase,
+                        hipStream_t stream) {
+  FwdParams p;
+  p.x = x; p.window = window; p.tw = tw; p.out = out; p.phase = phase;
+  p.B = B; p.L = L; p.clip_stride = clip_stride; p.T = T; p.hop = hop; p.center = center;
+  p.total_frames = B * T;
+  if (p.total_frames == 0) return 0;
+  // persistent-ish grid: up to 4 blocks (16 waves) per CU, each block a contiguous run of frames
+  long long max_blocks = (long long)num_cus() * 4;
+  long long fpb = (p.total_frames + max_blocks - 1) / max_blocks;
+  fpb = ((fpb + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK) * WAVES_PER_BLOCK;
+  if (fpb < 2 * WAVES_PER_BLOCK) fpb = 2 * WAVES_PER_BLOCK;
+  p.frames_per_block = fpb;
+  long long blocks = (p.total_frames + fpb - 1) / fpb;
+  if (phase)
+    hipLaunchKernelGGL(stft1024_fwd_kernel<true>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
+  else
+    hipLaunchKernelGGL(stft1024_fwd_kernel<false>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, long long B, long long T,
+                         const float* window, const float* env16, const float2* tw, float* y, hipStream_t stream) {
+  InvParams p = {};
+  p.X = X; p.mag = mag; p.phase = phase; p.window = window; p.env = env16; p.tw = tw; p.y = y;
+  p.B = B; p.T = T;
+  const long long nslots = T - 1;
+  if (B == 0 || nslots <= 0) return 0;
+  // choose the run length so that the grid has ~12 waves per CU but runs are >= 32 slots
+  long long target_waves = (long long)num_cus() * 12;
+  long long runs_per_clip = (target_waves + B - 1) / B;
+  if (runs_per_clip < 1) runs_per_clip = 1;
+  long long spr = (nslots + runs_per_clip - 1) / runs_per_clip;
+  if (spr < 32) spr = 32;
+  if (spr > nslots) spr = nslots;
+  runs_per_clip = (nslots + spr - 1) / spr;
+  p.runs_per_clip = runs_per_clip;
+  p.slots_per_run = spr;
+  long long waves = B * runs_per_clip;
+  long long blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  if (X)
+    hipLaunchKernelGGL(istft1024_ola_kernel<IN_COMPLEX>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
+  else
+    hipLaunchKernelGGL(istft1024_ola_kernel<IN_POLAR>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int launch_irfft1024_frames(const float2* X, const float* mag, const float* phase, long long nframes,
+                            const float* window, const float2* tw, float* y, hipStream_t stream) {
+  InvParams p = {};
+  p.X = X; p.mag = mag; p.phase = phase; p.window = window; p.tw = tw; p.y = y;
+  p.total_frames = nframes;
+  if (nframes == 0) return 0;
+  long long max_blocks = (long long)num_cus() * 4;
+  long long fpb = (nframes + max_blocks - 1) / max_blocks;
+  fpb = ((fpb + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK) * WAVES_PER_BLOCK;
+  p.frames_per_block = fpb;
+  long long blocks = (nframes + fpb - 1) / fpb;
+  if (X)
+    hipLaunchKernelGGL(irfft1024_frames_kernel<IN_COMPLEX>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
+  else
+    hipLaunchKernelGGL(irfft1024_frames_kernel<IN_POLAR>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // namespace at_hip

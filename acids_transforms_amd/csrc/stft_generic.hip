@@ -1,0 +1,214 @@
+// stft_generic.hip -- the same transforms as stft1024.hip for any power-of-two
+// n_fft in [8, 16384] and any hop (the reference accepts arbitrary sizes:
+// transforms/stft.py:67-75).  One workgroup per frame, radix-2 Stockham in LDS.
+// Correctness path for the non-default sizes the parity tests use; the
+// n_fft = 1024 kernels in stft1024.hip are the tuned ones.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace at_hip {
+
+struct GenFwdParams {
+  const float* x;
+  const float* window;
+  float2* out;
+  float* phase;
+  long long B, L, clip_stride, T;
+  int n_fft, hop, center;
+};
+
+__device__ __forceinline__ long long g_reflect(long long i, long long L) {
+  if (i < 0) i = -i;
+  if (i >= L) i = 2 * (L - 1) - i;
+  return i;
+}
+
+__device__ __forceinline__ float2 g_cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// Stockham radix-2 autosort FFT of M points held in `a` (ping) with scratch `b`.
+// Returns the pointer that holds the result.  sign = -1 forward, +1 inverse.
+__device__ float2* stockham(float2* a, float2* b, int M, float sign) {
+  for (int Ns = 1; Ns < M; Ns <<= 1) {
+    for (int j = threadIdx.x; j < M / 2; j += blockDim.x) {
+      int k = j & (Ns - 1);
+      float s, c;
+      sincospif(sign * (float)k / (float)Ns, &s, &c);  // angle = sign * 2*pi*k/(2 Ns)
+      float2 u = a[j];
+      float2 v = g_cmul(a[j + M / 2], make_float2(c, s));
+      int j0 = ((j - k) << 1) + k;
+      b[j0] = make_float2(u.x + v.x, u.y + v.y);
+      b[j0 + Ns] = make_float2(u.x - v.x, u.y - v.y);
+    }
+    __syncthreads();
+    float2* t = a;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+__global__ void rfft_generic_kernel(GenFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float2 sm[];
+  const int Nf = p.n_fft, M = Nf / 2;
+  float2* a = sm;
+  float2* b = sm + M;
+  const long long f = blockIdx.x;
+  const long long bidx = f / p.T, t = f - bidx * p.T;
+  const float* clip = p.x + bidx * p.clip_stride;
+  const long long start = t * (long long)p.hop - (p.center ? Nf / 2 : 0);
+  for (int n = threadIdx.x; n < M; n += blockDim.x) {
+    long long i0 = start + 2 * n, i1 = i0 + 1;
+    float x0, x1;
+    if (p.center) {
+      x0 = clip[g_reflect(i0, p.L)];
+      x1 = clip[g_reflect(i1, p.L)];
+    } else {
+      x0 = (i0 < p.L) ? clip[i0] : 0.f;
+      x1 = (i1 < p.L) ? clip[i1] : 0.f;
+    }
+    a[n] = make_float2(x0 * p.window[2 * n], x1 * p.window[2 * n + 1]);
+  }
+  __syncthreads();
+  float2* Z = stockham(a, b, M, -1.0f);
+  const int Fb = M + 1;
+  float2* row = p.out + f * Fb;
+  float* prow = p.phase ? p.phase + f * Fb : nullptr;
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+    float2 zk = Z[k & (M - 1)];
+    float2 zp = Z[(M - k) & (M - 1)];
+    zp.y = -zp.y;
+    float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y + zp.y));
+    float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y - zp.y));
+    float s, c;
+    sincospif(-2.0f * (float)k / (float)Nf, &s, &c);
+    float2 wd = g_cmul(make_float2(c, s), d);
+    float2 X = make_float2(e.x + wd.y, e.y - wd.x);
+    if (k == M) X = make_float2(Z[0].x - Z[0].y, 0.f);
+    row[k] = X;
+    if (prow) prow[k] = atan2f(X.y, X.x);
+  }
+}
+
+struct GenInvParams {
+  const float2* X;
+  const float* mag;
+  const float* phase;
+  const float* window;
+  float* frames;  // (B*T, n_fft)
+  int n_fft;
+};
+
+__global__ void irfft_generic_kernel(GenInvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float2 sm[];
+  const int Nf = p.n_fft, M = Nf / 2, Fb = M + 1;
+  float2* a = sm;
+  float2* b = sm + M;
+  float2* xs = sm + 2 * M;  // staged spectrum, Fb entries
+  const long long f = blockIdx.x;
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+    float2 v;
+    if (p.X) {
+      v = p.X[f * Fb + k];
+    } else {
+      float s, c;
+      sincosf(p.phase[f * Fb + k], &s, &c);
+      float m = p.mag[f * Fb + k];
+      v = make_float2(m * c, m * s);
+    }
+    if (k == 0 || k == M) v.y = 0.f;
+    xs[k] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < M; k += blockDim.x) {
+    float2 xk = xs[k];
+    float2 xp = xs[M - k];
+    xp.y = -xp.y;
+    float2 e = make_float2(xk.x + xp.x, xk.y + xp.y);
+    float s, c;
+    sincospif(2.0f * (float)k / (float)Nf, &s, &c);  // conj(W_N^k)
+    float2 d = g_cmul(make_float2(xk.x - xp.x, xk.y - xp.y), make_float2(c, s));
+    a[k] = make_float2(e.x - d.y, e.y + d.x);
+  }
+  __syncthreads();
+  float2* z = stockham(a, b, M, +1.0f);
+  const float sc = 1.0f / (float)Nf;
+  float2* dst = reinterpret_cast<float2*>(p.frames + f * Nf);
+  for (int n = threadIdx.x; n < M; n += blockDim.x)
+    dst[n] = make_float2((z[n].x * sc) * p.window[2 * n], (z[n].y * sc) * p.window[2 * n + 1]);
+}
+
+struct OlaParams {
+  const float* frames;  // (B, T, n_fft)
+  const float* window;
+  float* y;             // (B, hop*(T-1))
+  long long B, T;
+  int n_fft, hop;
+};
+
+// gather-form overlap-add with torch.istft's envelope division and centre trim
+__global__ void ola_gather_kernel(OlaParams p) {
+  const long long out_len = (long long)p.hop * (p.T - 1);
+  const long long total = p.B * out_len;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / out_len, s = i - b * out_len;
+    const long long pp = s + p.n_fft / 2;  // position in the padded signal
+    long long t_hi = pp / p.hop;
+    if (t_hi > p.T - 1) t_hi = p.T - 1;
+    long long t_lo = (pp - p.n_fft + p.hop) / p.hop;  // ceil((pp - n_fft + 1)/hop)
+    if (pp - p.n_fft + 1 <= 0) t_lo = 0;
+    float acc = 0.f, env = 0.f;
+    for (long long t = t_lo; t <= t_hi; ++t) {
+      const int o = (int)(pp - t * p.hop);
+      if (o < 0 || o >= p.n_fft) continue;
+      acc += p.frames[(b * p.T + t) * p.n_fft + o];
+      const float w = p.window[o];
+      env += w * w;
+    }
+    p.y[i] = acc / env;
+  }
+}
+
+static int set_lds(const void* fn, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -5;
+  }
+  return 0;
+}
+
+int launch_rfft_generic(const float* x, long long B, long long L, long long clip_stride, long long T, int n_fft,
+                        int hop, int center, const float* window, float2* out, float* phase, hipStream_t stream) {
+  if (B * T == 0) return 0;
+  GenFwdParams p = {x, window, out, phase, B, L, clip_stride, T, n_fft, hop, center};
+  size_t lds = sizeof(float2) * (size_t)n_fft;  // 2 * M
+  if (set_lds((const void*)rfft_generic_kernel, lds)) return -5;
+  int threads = n_fft / 4 < 64 ? 64 : (n_fft / 4 > 256 ? 256 : n_fft / 4);
+  hipLaunchKernelGGL(rfft_generic_kernel, dim3((unsigned)(B * T)), dim3(threads), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int launch_irfft_generic(const float2* X, const float* mag, const float* phase, long long nframes, int n_fft,
+                         const float* window, float* frames, hipStream_t stream) {
+  if (nframes == 0) return 0;
+  GenInvParams p = {X, mag, phase, window, frames, n_fft};
+  size_t lds = sizeof(float2) * (size_t)(n_fft + n_fft / 2 + 2);
+  if (set_lds((const void*)irfft_generic_kernel, lds)) return -5;
+  int threads = n_fft / 4 < 64 ? 64 : (n_fft / 4 > 256 ? 256 : n_fft / 4);
+  hipLaunchKernelGGL(irfft_generic_kernel, dim3((unsigned)nframes), dim3(threads), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int launch_ola_gather(const float* frames, long long B, long long T, int n_fft, int hop, const float* window,
+                      float* y, hipStream_t stream) {
+  long long total = B * (long long)hop * (T - 1);
+  if (total <= 0) return 0;
+  OlaParams p = {frames, window, y, B, T, n_fft, hop};
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(ola_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // namespace at_hip

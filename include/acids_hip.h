@@ -1,0 +1,86 @@
+/*
+ * acids_hip.h -- C ABI of libacids_hip.so, the MI355X (gfx950) implementation
+ * of the spectral hot path of acids_transforms.
+ *
+ * The reference is pure Python on torch CPU ops and has no FFI layer
+ * (SURVEY.md 8b); every entry point below therefore cites the reference
+ * *call site* it replaces (paths relative to acids_transforms/).  A maintainer
+ * binds these with ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - complex64 arrays are interleaved float pairs (re, im);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     all work is asynchronous on that stream; nothing allocates or
+ *     synchronises except at_init();
+ *   - return value: 0 on success, a negative AT_E* code otherwise; nothing
+ *     throws across the boundary;
+ *   - shapes use the reference's conventions: audio (B, L) float32, spectra
+ *     (B, T, F) with F = n_fft/2 + 1, T = 1 + L / hop (center=True).
+ */
+#ifndef ACIDS_HIP_H
+#define ACIDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AT_OK 0
+#define AT_EINVAL (-1)     /* bad argument (size, null pointer, alignment) */
+#define AT_EUNSUPPORTED (-2) /* valid in the reference, not implemented here (e.g. non power-of-two n_fft) */
+#define AT_ENOTINIT (-3)   /* at_init() was not called for the current device */
+#define AT_EWORKSPACE (-4) /* workspace too small */
+#define AT_ELAUNCH (-5)    /* HIP launch / runtime error */
+
+int at_abi_version(void);
+const char *at_error_string(int code);
+
+/* One-time per-device setup (twiddle tables).  Synchronous; call before capture. */
+int at_init(int device);
+
+/* ---- K1/K2/K4: forward ------------------------------------------------ */
+/* torch.stft(x, n_fft, hop, window, center=True, pad_mode="reflect",
+ * onesided=True, return_complex=True).transpose(-2,-1)
+ *     replaces transforms/stft.py:98-104 and transforms/dgt.py:64-70.
+ * center=0: frame t starts at sample t*hop of its clip, zero padded past L
+ *     (utils/misc.py:148-165 frame()) then rfft(x*window):
+ *     replaces stft.py:249-253 / dgt.py:285-289 on OverlapAdd.forward output
+ *     (oadd.py:69-74) without materialising the frames.
+ * phase (optional, may be NULL): atan2(im, re) of every bin = the reference's
+ *     phase_buffer side effect (stft.py:103). */
+int at_stft_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
+                    int center, const float *window, float *out_complex, float *phase, void *stream);
+
+/* ---- K3/K5/K15: inverse ------------------------------------------------ */
+/* 16 x hop table of window^2 sums used by at_istft for n_fft=1024, hop=256
+ * (torch.istft's window envelope; stft.py:126-127).  env16: 16*hop floats. */
+int at_istft_envelope_table(const float *inv_window, int n_fft, int hop, float *env16, void *stream);
+
+size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop);
+
+/* torch.istft(X.transpose(-2,-1), n_fft, hop, window=inv_window, onesided=True)
+ *     replaces stft.py:120-128, dgt.py:86-93 (complex input: X != NULL), and
+ *     `x * exp(1j*phase)` + istft, stft.py:157-161 / dgt.py:152-154
+ *     (polar input: X == NULL, mag and phase given).
+ * y: (B, hop*(T-1)).  env16 may be NULL unless n_fft=1024 && hop=256. */
+int at_istft(const float *X_complex, const float *mag, const float *phase, int64_t B, int64_t T, int n_fft, int hop,
+             const float *inv_window, const float *env16, float *y, void *workspace, size_t workspace_bytes,
+             void *stream);
+
+/* torch.fft.irfft(X) * inv_window on (nframes, F) -> (nframes, n_fft)
+ *     replaces stft.py:260-266,308-310 / dgt.py:296-302,325-328. */
+int at_irfft_frames(const float *X_complex, const float *mag, const float *phase, int64_t nframes, int n_fft,
+                    const float *inv_window, float *frames, void *stream);
+
+/* ---- pointwise ----------------------------------------------------------- */
+/* x.angle() on n complex64 values: the phase_buffer of stft.py:103 / dgt.py:69,
+ * and hgi_phase_buffer of dgt.py:336. */
+int at_angle(const float *x_complex, int64_t n, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACIDS_HIP_H */
