@@ -4,8 +4,6 @@ Same class names and nn.Module API as the reference package; the arithmetic
 is hand-written HIP for gfx950 behind a C ABI (include/acids_hip.h).
 """
 from .transforms import *  # noqa: F401,F403
-from .transforms import (AudioTransform, ComposeAudioTransform, NotInvertibleError, STFT, RealtimeSTFT, DGT,
-                         RealtimeDGT)
 from ._lib import AcidsHipError, build  # noqa: F401
 
 __version__ = "0.1.0"

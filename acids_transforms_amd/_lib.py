@@ -29,8 +29,14 @@ _SIGNATURES = {
     "at_istft": [c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_sz, c_f],
     "at_irfft_frames": [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f],
     "at_angle": [c_f, c_i64, c_f, c_f],
+    "at_mel_project": [c_f, c_int, c_i64, c_i64, c_int, c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_flt, c_f, c_i64,
+                       c_i64, c_f],
+    "at_mag_pointwise": [c_f, c_int, c_i64, c_int, c_int, c_f, c_f, c_flt, c_f, c_f],
+    "at_stats_workspace_bytes": [],
+    "at_stats": [c_f, c_int, c_i64, c_int, c_flt, c_f, c_f, c_sz, c_f],
+    "at_affine": [c_f, c_i64, c_f, c_f, c_int, c_f, c_f],
 }
-_RESTYPES = {"at_error_string": ctypes.c_char_p, "at_istft_workspace_bytes": c_sz}
+_RESTYPES = {"at_error_string": ctypes.c_char_p, "at_istft_workspace_bytes": c_sz, "at_stats_workspace_bytes": c_sz}
 
 
 class AcidsHipError(RuntimeError):

@@ -1,0 +1,369 @@
+// mel.hip -- |X| -> filterbank contraction with fused contrast / normalise epilogue.
+//
+// Replaces (reference transforms/spectral_repr.py, transforms/mel.py):
+//   x.abs(); torch.matmul(mag, mel_bank); contrast; Normalize.forward      :215-226   (K8,K9,K10)
+//   Normalize.invert; invert_contrast; torch.matmul(mag, inverse_mel_bank) :228-240   (K10,K9,K11)
+//   MelSpectrogram = |stft|^2 @ fbank, channel-major output                 mel.py:43-44,68-73 (K12)
+//
+// The contraction is a dense [rows x K] . [K x N] GEMM in exact fp32 on the
+// matrix cores: v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 fma chain, so the
+// 1e-5 parity bound holds without any split-precision trick).
+//
+// Layout of one 512-thread workgroup (8 waves, one per CU):
+//   * wave w owns 16 output columns of a 128-column block; its slice of the
+//     bank (K x 16, <= 128 VGPRs) stays in registers for the whole launch;
+//   * the workgroup walks 32-row tiles of the input; |.| is taken once while
+//     the tile is staged in LDS (row stride 64q+4 floats: conflict-free
+//     ds_read_b64 A-fragments), double buffered, the next tile's global loads
+//     interleaved with the current tile's MFMAs; one barrier per tile;
+//   * epilogue straight from the accumulators (contrast, (x-offset)/scale).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/acids_hip.h"
+
+namespace at_hip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { A_COMPLEX_ABS = 0, A_COMPLEX_ABS2 = 1, A_REAL = 2, A_REAL_ABS = 3 };
+enum { C_NONE = 0, C_LOG1P = 1, C_LOG = 2, C_LOG10 = 3 };
+
+struct MelParams {
+  const void* A;       // rows x K  (complex64 or float32), row stride lda elements
+  const float* Bm;     // K x N row-major, row stride ldb
+  float* out;
+  const float* offset; // device scalars (may be null => no normalisation)
+  const float* scale;
+  long long rows, lda, ld_out;
+  long long T;         // >0: channel-major store out[(r/T)*N*T + n*T + r%T]  (MFCC layout)
+  int K, N, ldb;
+  int a_kind, contrast, inverse;  // inverse: prologue (x*scale+offset, invert_contrast) on A instead of epilogue
+  float eps;
+  int rs;              // LDS row stride in floats
+  long long tiles_per_block;
+};
+
+constexpr int ROWS = 32;
+constexpr int THREADS = 512;
+
+__device__ __forceinline__ float contrast_fwd(float v, int mode, float eps) {
+  switch (mode) {
+    case C_LOG1P: return logf(1.0f + v);
+    case C_LOG: return logf(fmaxf(v, eps));
+    case C_LOG10: return log10f(fmaxf(v, eps));
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float contrast_inv(float v, int mode, float eps) {
+  switch (mode) {
+    case C_LOG1P: return expf(v) - 1.0f;
+    case C_LOG: return expf(v) - eps;
+    case C_LOG10: return powf(10.0f, v);
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float load_a(const MelParams& p, long long row, int k, float off, float sc) {
+  if (p.a_kind >= A_REAL) {
+    float v = reinterpret_cast<const float*>(p.A)[row * p.lda + k];
+    if (p.a_kind == A_REAL_ABS) v = fabsf(v);
+    if (p.inverse) {
+      if (p.offset) v = __fadd_rn(__fmul_rn(v, sc), off);
+      v = contrast_inv(v, p.contrast, p.eps);
+    }
+    return v;
+  }
+  float2 c = reinterpret_cast<const float2*>(p.A)[row * p.lda + k];
+  if (p.a_kind == A_COMPLEX_ABS2) return c.x * c.x + c.y * c.y;
+  return hypotf(c.x, c.y);
+}
+
+// stage rows [r0, r0+4) x all K of tile `tile` (piece c = r0/4) : issue loads
+template <int NL>
+__device__ __forceinline__ void piece_load(const MelParams& p, long long tile, int piece, float (&regs)[NL], float off,
+                                           float sc) {
+  const int tr = piece * 4 + (threadIdx.x >> 7);
+  const long long row = tile * ROWS + tr;
+  const int kseg = threadIdx.x & 127;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int k = kseg + 128 * i;
+    regs[i] = (row < p.rows && k < p.K) ? load_a(p, row, k, off, sc) : 0.0f;
+  }
+}
+
+template <int NL>
+__device__ __forceinline__ void piece_store(const MelParams& p, int piece, const float (&regs)[NL], float* buf) {
+  const int tr = piece * 4 + (threadIdx.x >> 7);
+  const int kseg = threadIdx.x & 127;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int k = kseg + 128 * i;
+    if (k < p.K) buf[tr * p.rs + k] = regs[i];
+  }
+}
+
+// KSTEPS = number of 4-deep MFMA steps (K_main = 4*KSTEPS <= K); NL = ceil(K/128) loads per thread per piece
+template <int KSTEPS, int NL>
+__global__ __launch_bounds__(THREADS) void mel_gemm_kernel(MelParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* buf0 = smem;
+  float* buf1 = smem + ROWS * p.rs;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 15, kk = lane >> 4;
+  const int col = blockIdx.y * 128 + wave * 16 + li;
+  const bool col_ok = col < p.N;
+  const int kmain = 4 * KSTEPS;
+
+  float off = 0.f, sc = 1.f;
+  if (p.offset) {
+    off = *p.offset;
+    sc = *p.scale;
+  }
+
+  // this wave's slice of the bank: step s = 2j+e multiplies k = 8j + 2kk + e
+  float breg[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const int k = 8 * (s >> 1) + 2 * kk + (s & 1);
+    breg[s] = col_ok ? p.Bm[(long long)k * p.ldb + col] : 0.0f;
+  }
+
+  const long long ntiles = (p.rows + ROWS - 1) / ROWS;
+  long long tile = (long long)blockIdx.x * p.tiles_per_block;
+  long long tile_end = tile + p.tiles_per_block;
+  if (tile_end > ntiles) tile_end = ntiles;
+  if (tile >= tile_end) return;
+
+  // prologue: stage the first tile
+  {
+    float regs[NL];
+    for (int c = 0; c < 8; ++c) {
+      piece_load<NL>(p, tile, c, regs, off, sc);
+      piece_store<NL>(p, c, regs, buf0);
+    }
+  }
+  __syncthreads();
+
+  float* cur = buf0;
+  float* nxt = buf1;
+  for (; tile < tile_end; ++tile) {
+    const bool has_next = tile + 1 < tile_end;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float* a0p = cur + li * p.rs + 2 * kk;
+    const float* a1p = cur + (16 + li) * p.rs + 2 * kk;
+    constexpr int CH = (KSTEPS / 2 + 7) / 8;  // j-iterations per staged piece
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float regs[NL];
+      if (has_next) piece_load<NL>(p, tile + 1, c, regs, off, sc);
+#pragma unroll
+      for (int jj = 0; jj < CH; ++jj) {
+        const int j = c * CH + jj;
+        if (j < KSTEPS / 2) {
+          const float2 a0 = *reinterpret_cast<const float2*>(a0p + 8 * j);
+          const float2 a1 = *reinterpret_cast<const float2*>(a1p + 8 * j);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[2 * j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[2 * j], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[2 * j + 1], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[2 * j + 1], acc1, 0, 0, 0);
+        }
+      }
+      if (has_next) piece_store<NL>(p, c, regs, nxt);
+    }
+    // K tail (k >= 4*KSTEPS) on the vector ALU; C/D layout: col = lane&15, row = 4*(lane>>4) + reg
+    for (int k = kmain; k < p.K; ++k) {
+      const float b = col_ok ? p.Bm[(long long)k * p.ldb + col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc0[r] = fmaf(cur[(4 * kk + r) * p.rs + k], b, acc0[r]);
+        acc1[r] = fmaf(cur[(16 + 4 * kk + r) * p.rs + k], b, acc1[r]);
+      }
+    }
+    // epilogue
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long row = tile * ROWS + h * 16 + 4 * kk + r;
+        float v = h ? acc1[r] : acc0[r];
+        if (!p.inverse) {
+          v = contrast_fwd(v, p.contrast, p.eps);
+          if (p.offset) v = (v - off) / sc;
+        }
+        if (row < p.rows && col_ok) {
+          if (p.T > 0) {
+            const long long b = row / p.T, t = row - b * p.T;
+            p.out[(b * p.N + col) * p.T + t] = v;
+          } else {
+            p.out[row * p.ld_out + col] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+}
+
+// fallback for shapes the MFMA kernel does not cover (K > 576): one thread per output
+__global__ void mel_gemm_simple_kernel(MelParams p) {
+  float off = 0.f, sc = 1.f;
+  if (p.offset) {
+    off = *p.offset;
+    sc = *p.scale;
+  }
+  const long long total = p.rows * p.N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / p.N;
+    const int col = (int)(i - row * p.N);
+    float acc = 0.f;
+    for (int k = 0; k < p.K; ++k) acc = fmaf(load_a(p, row, k, off, sc), p.Bm[(long long)k * p.ldb + col], acc);
+    if (!p.inverse) {
+      acc = contrast_fwd(acc, p.contrast, p.eps);
+      if (p.offset) acc = (acc - off) / sc;
+    }
+    if (p.T > 0) {
+      const long long b = row / p.T, t = row - b * p.T;
+      p.out[(b * p.N + col) * p.T + t] = acc;
+    } else {
+      p.out[row * p.ld_out + col] = acc;
+    }
+  }
+}
+
+// no projection: |x| (or real x) -> contrast -> normalise, or the inverse chain  (Magnitude with mel=False)
+struct PointParams {
+  const void* A;
+  float* out;
+  const float* offset;
+  const float* scale;
+  long long n;
+  int a_kind, contrast, inverse;
+  float eps;
+};
+
+__global__ void mag_pointwise_kernel(PointParams p) {
+  float off = 0.f, sc = 1.f;
+  if (p.offset) {
+    off = *p.offset;
+    sc = *p.scale;
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long long)gridDim.x * blockDim.x) {
+    float v;
+    if (p.a_kind >= A_REAL) {
+      v = reinterpret_cast<const float*>(p.A)[i];
+      if (p.a_kind == A_REAL_ABS) v = fabsf(v);
+    } else {
+      float2 c = reinterpret_cast<const float2*>(p.A)[i];
+      v = (p.a_kind == A_COMPLEX_ABS2) ? c.x * c.x + c.y * c.y : hypotf(c.x, c.y);
+    }
+    if (p.inverse) {
+      if (p.offset) v = __fadd_rn(__fmul_rn(v, sc), off);
+      v = contrast_inv(v, p.contrast, p.eps);
+    } else {
+      v = contrast_fwd(v, p.contrast, p.eps);
+      if (p.offset) v = (v - off) / sc;
+    }
+    p.out[i] = v;
+  }
+}
+
+template <int KSTEPS, int NL>
+static int launch_mel(const MelParams& p0, hipStream_t stream) {
+  MelParams p = p0;
+  const long long ntiles = (p.rows + ROWS - 1) / ROWS;
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  const int colblocks = (p.N + 127) / 128;
+  long long rowblocks = cus / colblocks;
+  if (rowblocks < 1) rowblocks = 1;
+  if (rowblocks > ntiles) rowblocks = ntiles;
+  p.tiles_per_block = (ntiles + rowblocks - 1) / rowblocks;
+  rowblocks = (ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
+  const size_t lds = sizeof(float) * 2 * ROWS * (size_t)p.rs;
+  auto kern = mel_gemm_kernel<KSTEPS, NL>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AT_ELAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)rowblocks, (unsigned)colblocks), dim3(THREADS), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+}  // namespace at_hip
+
+using namespace at_hip;
+
+extern "C" {
+
+int at_mel_project(const void* A, int a_kind, int64_t rows, int64_t lda, int K, const float* bank, int ldb, int N,
+                   int contrast, int inverse, const float* offset, const float* scale, float eps, float* out,
+                   int64_t ld_out, int64_t T_transposed, void* stream) {
+  if (rows < 0 || K <= 0 || N <= 0) return AT_EINVAL;
+  if (rows == 0) return AT_OK;
+  if (!A || !bank || !out) return AT_EINVAL;
+  if (a_kind < 0 || a_kind > 3 || contrast < 0 || contrast > 3) return AT_EINVAL;
+  if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
+  if (inverse && a_kind != A_REAL) return AT_EINVAL;
+  MelParams p;
+  p.A = A; p.Bm = bank; p.out = out; p.offset = offset; p.scale = scale;
+  p.rows = rows; p.lda = lda; p.ld_out = ld_out; p.T = T_transposed;
+  p.K = K; p.N = N; p.ldb = ldb; p.a_kind = a_kind; p.contrast = contrast; p.inverse = inverse; p.eps = eps;
+  p.rs = ((K - 4 + 63) / 64) * 64 + 4;
+  if (p.rs < K) p.rs += 64;
+  p.tiles_per_block = 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (K > 576 || K < 16) {
+    long long total = rows * (long long)N;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mel_gemm_simple_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+  }
+  const int nl = (K + 127) / 128;  // 1..5
+  // largest K_main = 4*KSTEPS <= K from {512, 256, 128, 64, 32, 16}
+#define AT_MEL_CASE(KS)                                        \
+  switch (nl) {                                                \
+    case 1: return launch_mel<KS, 1>(p, s);                    \
+    case 2: return launch_mel<KS, 2>(p, s);                    \
+    case 3: return launch_mel<KS, 3>(p, s);                    \
+    case 4: return launch_mel<KS, 4>(p, s);                    \
+    default: return launch_mel<KS, 5>(p, s);                   \
+  }
+  if (K >= 512) { AT_MEL_CASE(128) }
+  if (K >= 256) { AT_MEL_CASE(64) }
+  if (K >= 128) { AT_MEL_CASE(32) }
+  if (K >= 64) { AT_MEL_CASE(16) }
+  if (K >= 32) { AT_MEL_CASE(8) }
+  { AT_MEL_CASE(4) }
+#undef AT_MEL_CASE
+}
+
+int at_mag_pointwise(const void* A, int a_kind, int64_t n, int contrast, int inverse, const float* offset,
+                     const float* scale, float eps, float* out, void* stream) {
+  if (n < 0) return AT_EINVAL;
+  if (n == 0) return AT_OK;
+  if (!A || !out) return AT_EINVAL;
+  if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
+  PointParams p = {A, out, offset, scale, n, a_kind, contrast, inverse, eps};
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mag_pointwise_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+}  // extern "C"

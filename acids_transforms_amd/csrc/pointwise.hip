@@ -14,6 +14,94 @@ __global__ void angle_kernel(const float2* __restrict__ x, long long n, float* _
   }
 }
 
+// ---------------------------------------------------------------------------
+// global statistics of contrast(|x|) (or of a real tensor): min, max, sum, sum of squares.
+//   Normalize.scale_data          reference norm.py:25-38
+//   Magnitude.scale_data          reference spectral_repr.py:242-245 (stats of contrast(|x|), no mel)
+// Two launches: per-block partials, then one block folds them.  Sums are kept in fp64.
+// ---------------------------------------------------------------------------
+struct StatsParams {
+  const void* A;
+  long long n;
+  int a_kind;    // 0 complex |.|, 1 complex |.|^2, 2 real, 3 |real|
+  int contrast;  // 0 none, 1 log1p, 2 log, 3 log10
+  float eps;
+  double* partial;  // blocks x 4
+  int nblocks;
+};
+
+__device__ __forceinline__ float stats_value(const StatsParams& p, long long i) {
+  float v;
+  if (p.a_kind >= 2) {
+    v = reinterpret_cast<const float*>(p.A)[i];
+    if (p.a_kind == 3) v = fabsf(v);
+  } else {
+    float2 c = reinterpret_cast<const float2*>(p.A)[i];
+    v = (p.a_kind == 1) ? c.x * c.x + c.y * c.y : hypotf(c.x, c.y);
+  }
+  switch (p.contrast) {
+    case 1: return logf(1.0f + v);
+    case 2: return logf(fmaxf(v, p.eps));
+    case 3: return log10f(fmaxf(v, p.eps));
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ void block_fold(float mn, float mx, double s, double ss, double* dst) {
+  __shared__ float s_mn[4], s_mx[4];
+  __shared__ double s_s[4], s_ss[4];
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    s += __shfl_xor(s, o, 64);
+    ss += __shfl_xor(ss, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_mn[w] = mn; s_mx[w] = mx; s_s[w] = s; s_ss[w] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
+      mn = fminf(mn, s_mn[i]); mx = fmaxf(mx, s_mx[i]); s += s_s[i]; ss += s_ss[i];
+    }
+    dst[0] = mn; dst[1] = mx; dst[2] = s; dst[3] = ss;
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_partial_kernel(StatsParams p) {
+  float mn = INFINITY, mx = -INFINITY;
+  double s = 0.0, ss = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long long)gridDim.x * blockDim.x) {
+    float v = stats_value(p, i);
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+    s += (double)v;
+    ss += (double)v * (double)v;
+  }
+  block_fold(mn, mx, s, ss, p.partial + 4 * blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void stats_final_kernel(const double* partial, int nblocks, double* out4) {
+  float mn = INFINITY, mx = -INFINITY;
+  double s = 0.0, ss = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+    mn = fminf(mn, (float)partial[4 * i]);
+    mx = fmaxf(mx, (float)partial[4 * i + 1]);
+    s += partial[4 * i + 2];
+    ss += partial[4 * i + 3];
+  }
+  block_fold(mn, mx, s, ss, out4);
+}
+
+// (x - offset) / scale   and   x * scale + offset      reference norm.py:40-44
+__global__ void affine_kernel(const float* __restrict__ x, long long n, const float* offset, const float* scale,
+                              int inverse, float* __restrict__ out) {
+  const float off = *offset, sc = *scale;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = inverse ? __fadd_rn(__fmul_rn(x[i], sc), off) : (x[i] - off) / sc;
+}
+
 static inline unsigned grid_for(long long n, int block) {
   long long b = (n + block - 1) / block;
   if (b > 256 * 8) b = 256 * 8;  // grid-stride above 8 blocks per CU
@@ -33,6 +121,36 @@ int at_angle(const float* x_complex, int64_t n, float* out, void* stream) {
   if (!x_complex || !out) return AT_EINVAL;
   hipLaunchKernelGGL(angle_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)x_complex,
                      (long long)n, out);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+
+#define AT_STATS_MAX_BLOCKS 1024
+
+size_t at_stats_workspace_bytes(void) { return sizeof(double) * 4 * AT_STATS_MAX_BLOCKS; }
+
+int at_stats(const void* A, int a_kind, int64_t n, int contrast, float eps, double* out4, void* workspace,
+             size_t workspace_bytes, void* stream) {
+  if (n <= 0 || !A || !out4) return AT_EINVAL;
+  if (a_kind < 0 || a_kind > 3 || contrast < 0 || contrast > 3) return AT_EINVAL;
+  if (!workspace || workspace_bytes < at_stats_workspace_bytes()) return AT_EWORKSPACE;
+  long long blocks = (n + 256 * 8 - 1) / (256 * 8);
+  if (blocks > AT_STATS_MAX_BLOCKS) blocks = AT_STATS_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  StatsParams p = {A, (long long)n, a_kind, contrast, eps, (double*)workspace, (int)blocks};
+  hipLaunchKernelGGL(stats_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace,
+                     (int)blocks, out4);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+int at_affine(const float* x, int64_t n, const float* offset, const float* scale, int inverse, float* out,
+              void* stream) {
+  if (n < 0) return AT_EINVAL;
+  if (n == 0) return AT_OK;
+  if (!x || !offset || !scale || !out) return AT_EINVAL;
+  hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, offset,
+                     scale, inverse, out);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 

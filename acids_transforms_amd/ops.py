@@ -97,3 +97,109 @@ def angle(X):
     out = torch.empty(X.shape, dtype=torch.float32, device=X.device)
     check(lib().at_angle(ptr(X), X.numel(), ptr(out), stream_ptr()), "at_angle")
     return out
+
+
+_CONTRAST = {None: 0, "none": 0, "log1p": 1, "log": 2, "log10": 3}
+
+
+def contrast_code(mode):
+    if mode not in _CONTRAST:
+        raise TypeError("unknown contrast type %s" % mode)
+    return _CONTRAST[mode]
+
+
+def _a_kind(x, power=1):
+    if torch.is_complex(x):
+        return 1 if power == 2 else 0
+    return 3
+
+
+def _prep_in(x):
+    if torch.is_complex(x):
+        if x.dtype != torch.complex64:
+            x = x.to(torch.complex64)
+    elif x.dtype != torch.float32:
+        x = x.float()
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def mel_forward(x, bank, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1, channel_major_T=0):
+    """normalise(contrast(|x|^power @ bank)); x: (..., K) complex64/float32, bank: (K, N).
+    channel_major_T = T > 0 stores (..., N, T) for x of shape (..., T, K) (MelSpectrogram layout)."""
+    require_device(x, bank)
+    x = _prep_in(x)
+    K, N = bank.shape[-2], bank.shape[-1]
+    assert x.shape[-1] == K, "last dim of the input (%d) must match the bank (%d)" % (x.shape[-1], K)
+    bank2 = bank.reshape(K, N)
+    bank2 = bank2 if bank2.is_contiguous() else bank2.contiguous()
+    rows = x.numel() // K
+    if channel_major_T:
+        out = torch.empty(x.shape[:-2] + (N, channel_major_T), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    check(lib().at_mel_project(ptr(x), _a_kind(x, power), rows, K, K, ptr(bank2), N, N, contrast_code(contrast), 0,
+                               ptr(offset), ptr(scale), eps, ptr(out), N, channel_major_T, stream_ptr()),
+          "at_mel_project")
+    return out
+
+
+def mel_inverse(y, inv_bank, contrast=None, offset=None, scale=None, eps=1.1920929e-07):
+    """invert_contrast(y*scale+offset) @ inv_bank; y: (..., K) float32, inv_bank: (K, N)."""
+    require_device(y, inv_bank)
+    y = _prep_in(y)
+    K, N = inv_bank.shape[-2], inv_bank.shape[-1]
+    assert y.shape[-1] == K
+    b2 = inv_bank.reshape(K, N)
+    b2 = b2 if b2.is_contiguous() else b2.contiguous()
+    rows = y.numel() // K
+    out = torch.empty(y.shape[:-1] + (N,), dtype=torch.float32, device=y.device)
+    check(lib().at_mel_project(ptr(y), 2, rows, K, K, ptr(b2), N, N, contrast_code(contrast), 1, ptr(offset),
+                               ptr(scale), eps, ptr(out), N, 0, stream_ptr()), "at_mel_project")
+    return out
+
+
+def mag_pointwise(x, contrast=None, offset=None, scale=None, eps=1.1920929e-07, inverse=False):
+    """mel=False chains: normalise(contrast(|x|)) or invert_contrast(x*scale+offset)."""
+    require_device(x)
+    x = _prep_in(x)
+    kind = 2 if inverse else _a_kind(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().at_mag_pointwise(ptr(x), kind, x.numel(), contrast_code(contrast), int(inverse), ptr(offset),
+                                 ptr(scale), eps, ptr(out), stream_ptr()), "at_mag_pointwise")
+    return out
+
+
+def stats(x, contrast=None, eps=1.1920929e-07, take_abs=True):
+    """float64 tensor [min, max, sum, sumsq] of contrast(|x|) (take_abs) or of real x."""
+    require_device(x)
+    x = _prep_in(x)
+    kind = _a_kind(x) if (take_abs or torch.is_complex(x)) else 2
+    out = torch.empty(4, dtype=torch.float64, device=x.device)
+    wsb = lib().at_stats_workspace_bytes()
+    ws = torch.empty(wsb // 8, dtype=torch.float64, device=x.device)
+    check(lib().at_stats(ptr(x), kind, x.numel(), contrast_code(contrast), eps, ptr(out), ptr(ws), wsb, stream_ptr()),
+          "at_stats")
+    return out
+
+
+def affine(x, offset, scale, inverse=False):
+    require_device(x, offset, scale)
+    x = _prep_in(x)
+    out = torch.empty_like(x)
+    check(lib().at_affine(ptr(x), x.numel(), ptr(offset), ptr(scale), int(inverse), ptr(out), stream_ptr()), "at_affine")
+    return out
+
+
+def mel_forward_real(x, mat, offset=None, scale=None, channel_major_T=0):
+    """normalise(x @ mat) for real x (no |.|): second projection of the MFCC extension."""
+    require_device(x, mat)
+    x = _prep_in(x)
+    K, N = mat.shape
+    rows = x.numel() // K
+    if channel_major_T:
+        out = torch.empty(x.shape[:-2] + (N, channel_major_T), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    check(lib().at_mel_project(ptr(x), 2, rows, K, K, ptr(mat), N, N, 0, 0, ptr(offset), ptr(scale), 0.0, ptr(out), N,
+                               channel_major_T, stream_ptr()), "at_mel_project")
+    return out

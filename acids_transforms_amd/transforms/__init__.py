@@ -1,5 +1,11 @@
-from .base import *  # noqa: F401,F403
 from .base import (AudioTransform, ComposeAudioTransform, NotInvertibleError, InversionEnumType,
                    apply_transform_to_list, apply_invert_transform_to_list)
 from .stft import STFT, RealtimeSTFT
 from .dgt import DGT, RealtimeDGT
+from .norm import Normalize
+from .spectral_repr import Magnitude
+from .mel import MFCC
+
+__all__ = ["AudioTransform", "ComposeAudioTransform", "NotInvertibleError", "InversionEnumType",
+           "apply_transform_to_list", "apply_invert_transform_to_list", "STFT", "RealtimeSTFT", "DGT", "RealtimeDGT",
+           "Normalize", "Magnitude", "MFCC"]

@@ -1,0 +1,80 @@
+"""Normalize: global scalar affine normalisation (reference transforms/norm.py:12-99).
+
+`scale_data` is one fused device reduction (min / max / sum / sum of squares in
+fp64, pointwise.hip) -- no host synchronisation; `forward` / `invert` are one
+elementwise kernel, and `Magnitude` / `MFCC` fold them into their GEMM epilogue.
+"""
+from typing import Union
+
+import torch
+
+from .. import ops
+from .base import AudioTransform
+
+__all__ = ["Normalize"]
+
+MagnitudeModeType = Union[None, str]
+
+
+def stats_to_affine(st: torch.Tensor, n: int, mode: str):
+    """[min, max, sum, sumsq] (fp64, on device) -> (offset, scale) 0-dim fp32 tensors
+    with the reference's definitions (norm.py:25-38)."""
+    mn, mx = st[0].float(), st[1].float()
+    if mode == "unipolar":
+        return mn, mx - mn                       # (x - min).max() == fl(max - min)
+    if mode == "bipolar":
+        offset = (mx + mn) / 2
+        return offset, mx - offset
+    if mode == "gaussian":
+        mean = st[2] / n
+        var = (st[3] - st[2] * mean) / max(n - 1, 1)   # unbiased, like Tensor.std()
+        return mean.float(), var.clamp_min(0).sqrt().float()
+    raise ValueError("unknown normalisation mode %s" % mode)
+
+
+class Normalize(AudioTransform):
+    scriptable = False
+
+    def __repr__(self):
+        return "Normalize(mode=%s)" % self.mode
+
+    def __init__(self, mode: MagnitudeModeType = "gaussian"):
+        super().__init__()
+        self.mode = mode
+        self.needs_scaling = True
+        self.register_buffer("offset", torch.zeros(0))
+        self.register_buffer("scale", torch.ones(1))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for k in ("offset", "scale"):     # shapes change once scaled ((0,)/(1,) -> 0-dim)
+            if prefix + k in state_dict:
+                self._buffers[k] = torch.zeros_like(state_dict[prefix + k])
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def set_affine(self, offset: torch.Tensor, scale: torch.Tensor) -> None:
+        self.offset, self.scale = offset, scale
+        self.needs_scaling = False
+
+    def scale_data(self, x: torch.Tensor) -> None:
+        if self.mode in ("unipolar", "bipolar", "gaussian"):
+            st = ops.stats(x, take_abs=False)
+            self.set_affine(*stats_to_affine(st, x.numel(), self.mode))
+        self.needs_scaling = False
+
+    def _params(self, x):
+        if self.offset.numel() != 1:
+            raise RuntimeError("Normalize used before scale_data(): offset has shape %s" % (tuple(self.offset.shape),))
+        if self.offset.device != x.device:
+            self.to(x.device)
+        return self.offset, self.scale
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        off, sc = self._params(x)
+        return ops.affine(x, off, sc, inverse=False)
+
+    def invert(self, x: torch.Tensor, inversion_mode=None, **kwargs) -> torch.Tensor:
+        off, sc = self._params(x)
+        return ops.affine(x, off, sc, inverse=True)
+
+    def get_normalization_modes(self):
+        return ["unipolar", "bipolar", "gaussian"]

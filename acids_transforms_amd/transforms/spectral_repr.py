@@ -1,0 +1,123 @@
+"""Magnitude representation: |X| -> (mel filterbank) -> contrast -> Normalize.
+
+Drop-in for the reference's `Magnitude` (transforms/spectral_repr.py:143-258):
+same constructor, buffers (`eps`, `mel_bank` (1,F,N), `inverse_mel_bank`
+(1,N,F), `norm.offset`, `norm.scale`) and quirks (scale_data ignores the mel
+projection, :242-245; inputs of any rank; keep_nyquist=False drops output bin 0
+and pads at the end).  `n_mels` is an added optional argument: the reference
+always builds an n_bins x n_bins bank (:173-178), which stays the default.
+forward / invert are one fused MFMA kernel each (mel.hip).
+"""
+from typing import Union
+
+import torch
+
+from .. import ops
+from ..utils.melbank import melscale_fbanks
+from .base import AudioTransform, InversionEnumType
+from .norm import Normalize, stats_to_affine
+
+__all__ = ["Magnitude"]
+
+ContrastModeType = Union[None, str]
+
+
+class _Identity(AudioTransform):
+    mode = None
+
+
+class Magnitude(AudioTransform):
+    scriptable = False
+    invertible = True
+    needs_scaling = True
+
+    def __repr__(self):
+        if self.mel:
+            return "Magnitude(mel=%s, n_fft=%s, norm=%s)" % (self.mel, self.n_fft, self.norm.mode)
+        return "Magnitude(norm=%s)" % self.norm.mode
+
+    def __init__(self, sr: int = 44100, mode: Union[str, None] = "unipolar", contrast: ContrastModeType = "log1p",
+                 mel: bool = True, n_fft: int = 1024, dtype: torch.dtype = None, eps: float = None,
+                 keep_nyquist: bool = True, n_mels: int = None):
+        super().__init__(sr=sr)
+        self.norm = _Identity() if (mode is None or mode == "none") else Normalize(mode)
+        self.contrast_mode = contrast
+        self.mel = mel
+        self.n_fft = n_fft
+        if dtype is None:
+            dtype = torch.get_default_dtype()
+        if eps is None:
+            eps = torch.finfo(dtype).eps
+        self.register_buffer("eps", torch.tensor(eps))
+        self._eps = float(eps)
+        self.keep_nyquist = keep_nyquist
+        assert sr is not None
+        assert n_fft is not None
+        n_bins = n_fft // 2 + 1
+        fft_scale = torch.arange(n_bins) / n_fft * sr
+        if not self.keep_nyquist:
+            fft_scale = fft_scale[..., 1:]
+        bank = melscale_fbanks(n_bins, fft_scale[0], fft_scale[-1], n_bins if n_mels is None else int(n_mels), sr)
+        self._set_bank(bank)
+
+    def _set_bank(self, bank: torch.Tensor) -> None:
+        """Forward bank: every filter (column) scaled to unit sum; inverse bank: every
+        frequency row scaled to unit sum, transposed.  All-zero columns/rows are left alone."""
+        col = bank.sum(0)
+        fwd = bank / torch.where(col != 0, col, torch.ones_like(col)).unsqueeze(0)
+        row = bank.sum(1)
+        inv = bank / torch.where(row != 0, row, torch.ones_like(row)).unsqueeze(1)
+        self.register_buffer("mel_bank", fwd.unsqueeze(0))
+        self.register_buffer("inverse_mel_bank", inv.transpose(-2, -1).unsqueeze(0))
+
+    # ------------------------------------------------------------------
+    def _follow(self, x):
+        if self.eps.device != x.device:
+            self.to(x.device)
+
+    def _affine(self):
+        if isinstance(self.norm, Normalize):
+            if self.norm.offset.numel() != 1:
+                raise RuntimeError("Magnitude used before scale_data(): norm.offset has shape %s"
+                                   % (tuple(self.norm.offset.shape),))
+            return self.norm.offset, self.norm.scale
+        return None, None
+
+    def contrast(self, mag: torch.Tensor) -> torch.Tensor:
+        ops.contrast_code(self.contrast_mode)   # TypeError on unknown modes, like the reference
+        return ops.mag_pointwise(mag, self.contrast_mode, eps=self._eps)
+
+    def invert_contrast(self, mag: torch.Tensor) -> torch.Tensor:
+        ops.contrast_code(self.contrast_mode)
+        return ops.mag_pointwise(mag, self.contrast_mode, eps=self._eps, inverse=True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._follow(x)
+        off, sc = self._affine()
+        if self.mel:
+            mag = ops.mel_forward(x, self.mel_bank, self.contrast_mode, off, sc, self._eps)
+        else:
+            mag = ops.mag_pointwise(x, self.contrast_mode, off, sc, self._eps)
+        if not self.keep_nyquist:
+            mag = mag[..., 1:]
+        return mag
+
+    def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        self._follow(x)
+        off, sc = self._affine()
+        if not self.keep_nyquist:
+            # reference order: Normalize.invert, zero-pad the LAST bin, then invert_contrast (+ bank)
+            if off is not None:
+                x = ops.affine(x, off, sc, inverse=True)
+            x = torch.cat([x, torch.zeros(x.shape[:-1] + (1,), device=x.device, dtype=x.dtype)], -1)
+            off = sc = None
+        if self.mel:
+            return ops.mel_inverse(x, self.inverse_mel_bank, self.contrast_mode, off, sc, self._eps)
+        return ops.mag_pointwise(x, self.contrast_mode, off, sc, self._eps, inverse=True)
+
+    def scale_data(self, x: torch.Tensor) -> None:
+        """Statistics of contrast(|x|) -- the mel projection is NOT applied (reference :242-245)."""
+        self._follow(x)
+        if isinstance(self.norm, Normalize):
+            st = ops.stats(x, self.contrast_mode, self._eps, take_abs=True)
+            self.norm.set_affine(*stats_to_affine(st, x.numel(), self.norm.mode))

@@ -75,6 +75,39 @@ int at_istft(const float *X_complex, const float *mag, const float *phase, int64
 int at_irfft_frames(const float *X_complex, const float *mag, const float *phase, int64_t nframes, int n_fft,
                     const float *inv_window, float *frames, void *stream);
 
+/* ---- K8-K12: magnitude / mel projection ---------------------------------- */
+/* a_kind: 0 = complex64 input, |.| taken on load; 1 = complex64, |.|^2 (power=2);
+ *         2 = float32 input; 3 = float32 input, |.| taken.   contrast: 0 none, 1 log1p, 2 log, 3 log10.
+ * forward (inverse=0):  out = normalise(contrast(A' @ bank))
+ *     replaces  x.abs(); torch.matmul(mag, mel_bank); contrast; Normalize.forward
+ *     (spectral_repr.py:215-226, norm.py:40-41) and, with a_kind=1 and
+ *     T_transposed=T, torchaudio MelSpectrogram's |stft|^2 @ fbank with its
+ *     channel-major (..., n_mels, T) output (mel.py:43-44, 68-73).
+ * inverse (inverse=1, a_kind=2): out = invert_contrast(A*scale+offset) @ bank
+ *     replaces  Normalize.invert; invert_contrast; matmul(mag, inverse_mel_bank)
+ *     (spectral_repr.py:228-240, norm.py:43-44).
+ * A: rows x K with row stride lda (elements); bank: K x N row-major, stride ldb;
+ * out: rows x N with stride ld_out, or (rows/T, N, T) when T_transposed > 0.
+ * offset/scale: device scalars, both NULL = no normalisation.  Exact fp32 MFMA. */
+int at_mel_project(const void *A, int a_kind, int64_t rows, int64_t lda, int K, const float *bank, int ldb, int N,
+                   int contrast, int inverse, const float *offset, const float *scale, float eps, float *out,
+                   int64_t ld_out, int64_t T_transposed, void *stream);
+
+/* Magnitude with mel=False: the same chains without the projection (n elements). */
+int at_mag_pointwise(const void *A, int a_kind, int64_t n, int contrast, int inverse, const float *offset,
+                     const float *scale, float eps, float *out, void *stream);
+
+/* {min, max, sum, sum of squares} (fp64) of contrast(|A|) over n elements:
+ *     Normalize.scale_data (norm.py:25-38) / Magnitude.scale_data (spectral_repr.py:242-245). */
+size_t at_stats_workspace_bytes(void);
+int at_stats(const void *A, int a_kind, int64_t n, int contrast, float eps, double *out4, void *workspace,
+             size_t workspace_bytes, void *stream);
+
+/* Normalize.forward (inverse=0): (x-offset)/scale;  Normalize.invert (inverse=1): x*scale+offset
+ *     (norm.py:40-44); offset/scale are device scalars. */
+int at_affine(const float *x, int64_t n, const float *offset, const float *scale, int inverse, float *out,
+              void *stream);
+
 /* ---- pointwise ----------------------------------------------------------- */
 /* x.angle() on n complex64 values: the phase_buffer of stft.py:103 / dgt.py:69,
  * and hgi_phase_buffer of dgt.py:336. */

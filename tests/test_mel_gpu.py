@@ -1,0 +1,170 @@
+"""GPU parity: Magnitude (mel projection + contrast + Normalize), Normalize, MFCC.
+fp32 tolerance 1e-5 normwise (north_star); the projection runs on exact-fp32 MFMA."""
+import numpy as np
+import pytest
+import torch
+
+import acids_transforms_amd as A
+from conftest import rel_max
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+T_ = torch.from_numpy
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def test_magnitude_all_modes_golden(golden, dev):
+    g = golden("g7_magnitude")
+    X = T_(g["X"]).to(dev)
+    for c in ["log1p", "log", "log10", "none"]:
+        for mode in ["unipolar", "bipolar", "gaussian", "none"]:
+            for mel in [1, 0]:
+                k = "%s_%s_%d" % (c, mode, mel)
+                m = A.Magnitude(mode=mode, contrast=c, mel=bool(mel), n_fft=128)
+                m._set_bank(T_(g["bank"]))
+                m = m.to(dev)
+                assert np.array_equal(cpu(m.mel_bank), g["mel_bank"])
+                assert np.array_equal(cpu(m.inverse_mel_bank), g["inverse_mel_bank"])
+                m.scale_data(X)
+                if mode != "none":
+                    assert abs(float(m.norm.offset) - float(g["offset_" + k])) <= 2e-6 * max(1, abs(float(g["offset_" + k]))), k
+                    assert abs(float(m.norm.scale) - float(g["scale_" + k])) <= 2e-6 * abs(float(g["scale_" + k])), k
+                    assert m.norm.offset.dim() == 0
+                y = m(X)
+                assert y.shape == g["y_" + k].shape
+                assert rel_max(cpu(y), g["y_" + k]) < TOL, k
+                xi = m.invert(T_(g["y_" + k]).to(dev))
+                assert rel_max(cpu(xi), g["inv_" + k]) < 2e-5, k     # exp() amplifies 1 ulp of its argument
+    m = A.Magnitude(mode="none", contrast="log1p", mel=True, n_fft=128)
+    m._set_bank(T_(g["bank"]))
+    m = m.to(dev)
+    y2, y1 = m(X[0]), m(X[0, 0])
+    assert y2.shape == g["y_2d"].shape and rel_max(cpu(y2), g["y_2d"]) < TOL
+    assert y1.shape == g["y_1d"].shape and rel_max(cpu(y1), g["y_1d"]) < TOL
+
+
+def test_magnitude_513_golden(golden, dev):
+    g = golden("g7_magnitude")
+    m = A.Magnitude(mode="unipolar", contrast="log1p", mel=True)
+    m._set_bank(T_(g["bank513"]))
+    m = m.to(dev)
+    X = T_(g["X513"]).to(dev)
+    m.scale_data(X)
+    assert abs(float(m.norm.offset) - float(g["offset513"])) < 1e-6
+    y = m(X)
+    assert rel_max(cpu(y), g["y513"]) < TOL
+    assert rel_max(cpu(m.invert(T_(g["y513"]).to(dev))), g["inv513"]) < 2e-5
+
+
+def test_compose_stft_magnitude_golden(golden, dev):
+    g = golden("g7_compose")
+    mag = A.Magnitude(mode="unipolar", contrast="log1p", mel=True)
+    mag._set_bank(T_(g["bank"]))
+    comp = (A.STFT() + mag).to(dev)
+    assert isinstance(comp, A.ComposeAudioTransform) and comp.needs_scaling
+    x = T_(g["x"]).to(dev)
+    comp.scale_data(x)
+    assert abs(float(comp[1].norm.scale) - float(g["scale"])) < 1e-5 * float(g["scale"])
+    y = comp(x)
+    assert rel_max(cpu(y), g["y"]) < TOL
+    assert rel_max(cpu(comp[1].invert(T_(g["y"]).to(dev))), g["mag_inv"]) < 2e-5
+    with pytest.raises(TypeError):
+        comp + 3
+
+
+def test_normalize_golden(golden, dev):
+    g = golden("g9_normalize")
+    x = T_(g["x"]).to(dev)
+    for mode in ["unipolar", "bipolar", "gaussian"]:
+        nm = A.Normalize(mode).to(dev)
+        with pytest.raises(RuntimeError):
+            nm(x)                       # unscaled module raises, like the reference
+        nm.scale_data(x)
+        assert abs(float(nm.offset) - float(g["offset_" + mode])) < 1e-6
+        assert abs(float(nm.scale) - float(g["scale_" + mode])) < 1e-6
+        y = nm(x)
+        assert rel_max(cpu(y), g["y_" + mode]) < TOL
+        assert rel_max(cpu(nm.invert(T_(g["y_" + mode]).to(dev))), g["inv_" + mode]) < TOL
+    # the reference's own known-answer asserts (norm.py:59-67)
+    nm = A.Normalize("unipolar").to(dev)
+    nm.scale_data(x)
+    y = nm(x)
+    assert float(y.min()) == 0.0 and float(y.max()) == 1.0
+    nm = A.Normalize("bipolar").to(dev)
+    nm.scale_data(x)
+    y = nm(x)
+    assert float(y.min()) == -1.0 and float(y.max()) == 1.0
+
+
+@pytest.mark.parametrize("rows,K,N", [(1000, 513, 128), (77, 513, 513), (33, 257, 80), (5, 129, 129), (64, 65, 40),
+                                       (3, 33, 16), (200, 17, 17), (9, 1025, 64), (1, 513, 1), (4097, 513, 130),
+                                       (40, 128, 513), (31, 100, 37)])
+def test_projection_vs_oracle_shapes(dev, rows, K, N):
+    g = torch.Generator().manual_seed(rows * 7 + K)
+    X = (torch.randn(rows, K, generator=g) * torch.exp(2j * np.pi * torch.rand(rows, K, generator=g))).to(torch.complex64)
+    bank = torch.rand(K, N, generator=g) * (torch.rand(K, N, generator=g) < 0.3)
+    from acids_transforms_amd import ops
+    y = ops.mel_forward(X.to(dev), bank.to(dev), "log1p")
+    yr = torch.log(1 + torch.matmul(X.abs().double(), bank.double())).float()
+    assert rel_max(cpu(y), yr.numpy()) < TOL
+    yi = ops.mel_inverse(yr.to(dev), bank.t().contiguous().to(dev), "log1p")
+    yir = torch.matmul((torch.exp(yr) - 1).double(), bank.t().double()).float()
+    assert rel_max(cpu(yi), yir.numpy()) < TOL
+    yp = ops.mel_forward(X.to(dev), bank.to(dev), None, power=2)
+    ypr = torch.matmul((X.abs().double() ** 2), bank.double()).float()
+    assert rel_max(cpu(yp), ypr.numpy()) < TOL
+
+
+def test_default_bank_and_nmels(dev):
+    m = A.Magnitude().to(dev)            # reference default: 513 x 513 HTK bank, 1019 non-zeros
+    fb = O.magnitude_default_bank(44100, 1024)
+    fwd, inv = O.magnitude_banks(fb)
+    assert np.array_equal(cpu(m.mel_bank), fwd.numpy()) and np.array_equal(cpu(m.inverse_mel_bank), inv.numpy())
+    torch.manual_seed(1)
+    x = torch.randn(4, 8192) * 0.1
+    s = A.STFT().to(dev)
+    X = s(x.to(dev))
+    m.scale_data(X)
+    Xr = O.stft_forward(x, O.hann_window(1024), 1024, 256)
+    off, sc = O.magnitude_scale_stats(Xr, "log1p", "unipolar")
+    yr = O.magnitude_forward(Xr, fwd, "log1p", off, sc)
+    assert rel_max(cpu(m(X)), yr.numpy()) < TOL
+    m128 = A.Magnitude(n_mels=128, mode=None).to(dev)   # BASELINE config 2's "mel=128"
+    y = m128(X)
+    assert y.shape == (4, 33, 128)
+    fb128 = O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100)
+    fwd128, _ = O.magnitude_banks(fb128)
+    assert rel_max(cpu(y), O.magnitude_forward(Xr, fwd128, "log1p").numpy()) < TOL
+    # keep_nyquist=False: drops output bin 0, pads the last one on the way back
+    mk = A.Magnitude(mode=None, keep_nyquist=False).to(dev)
+    yk = mk(X)
+    assert yk.shape[-1] == 512 and mk.invert(yk).shape[-1] == 513
+
+
+def test_mfcc_melspectrogram(dev):
+    torch.manual_seed(2)
+    x = torch.randn(3, 2, 6000) * 0.1
+    f = A.MFCC().to(dev)
+    y = f(x.to(dev))
+    yr = O.melspectrogram(x, 44100, 1024, 256, 128, 2.0)
+    assert y.shape == yr.shape == (3, 2, 128, 24)
+    assert rel_max(cpu(y), yr.numpy()) < TOL
+    with pytest.raises(A.NotInvertibleError):
+        f.invert(y)
+    _, tt = f.forward_with_time(x.to(dev), torch.zeros(3, 2, device=dev))
+    assert tt.shape == (3, 2, 128)       # the reference counts n_mels as chunks (mel.py:49)
+    fn = A.MFCC(norm_mode="gaussian").to(dev)
+    fn.scale_data(x.to(dev))             # statistics of the raw input, as the reference does
+    off, sc = O.normalize_stats(x, "gaussian")
+    assert rel_max(cpu(fn(x.to(dev))), ((yr - off) / sc).numpy()) < TOL
+    # build extension: true MFCC(40) = DCT-II(ortho) of 10 log10(mel power)
+    f40 = A.MFCC(n_mfcc=40).to(dev)
+    c = f40(x.to(dev))
+    db = 10.0 * torch.log10(torch.clamp(yr, min=1e-10)).transpose(-1, -2)
+    cr = O.mfcc_dct(db, 40).transpose(-1, -2)
+    assert c.shape == cr.shape == (3, 2, 40, 24)
+    assert rel_max(cpu(c), cr.numpy()) < 2e-5

@@ -1,5 +1,7 @@
 """Quick kernel timing (dev tool, not the bench contract): STFT fwd / ISTFT at BASELINE config 2 size."""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import acids_transforms_amd as A
 
