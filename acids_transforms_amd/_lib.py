@@ -35,8 +35,16 @@ _SIGNATURES = {
     "at_stats_workspace_bytes": [],
     "at_stats": [c_f, c_int, c_i64, c_int, c_flt, c_f, c_f, c_sz, c_f],
     "at_affine": [c_f, c_i64, c_f, c_f, c_int, c_f, c_f],
+    "at_pghi_gradients": [c_f, c_i64, c_int, c_int, c_flt, c_int, c_int, c_flt, c_f, c_f, c_f, c_f],
+    "at_pghi_offline_workspace_bytes": [c_i64, c_int, c_int],
+    "at_pghi_offline": [c_f, c_i64, c_int, c_int, c_flt, c_int, c_int, c_flt, c_flt, c_f, c_f, c_sz, c_f, c_f, c_f],
+    "at_pghi_rt_workspace_bytes": [c_int, c_int, c_int],
+    "at_pghi_realtime": [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_flt, c_int, c_int, c_flt, c_flt, c_f, c_f, c_f,
+                         c_f, c_sz, c_f],
+    "at_rt_update_buffers": [c_f, c_f, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
 }
-_RESTYPES = {"at_error_string": ctypes.c_char_p, "at_istft_workspace_bytes": c_sz, "at_stats_workspace_bytes": c_sz}
+_RESTYPES = {"at_error_string": ctypes.c_char_p, "at_istft_workspace_bytes": c_sz, "at_stats_workspace_bytes": c_sz,
+             "at_pghi_offline_workspace_bytes": c_sz, "at_pghi_rt_workspace_bytes": c_sz}
 
 
 class AcidsHipError(RuntimeError):

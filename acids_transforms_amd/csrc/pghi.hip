@@ -1,0 +1,541 @@
+// pghi.hip -- phase-gradient heap integration (PGHI) on gfx950.
+//
+// Replaces the reference's pure-Python heap loops:
+//   DGT.modgabphasegrad / pghi / perform_hgi              transforms/dgt.py:156-236   (K13, K14)
+//   RealtimeDGT.modgabphasegrad / pghi / perform_hgi      transforms/dgt.py:338-466
+//   utils/heapq.py:9-59 (binary min-heap on keys only, strict '<', right child on ties)
+//
+// The integration order is part of the contract: it is
+// defined by exact fp32 compares of magnitudes and by the heap's tie-breaking,
+// so the heap here is the same array-embedded binary heap with the same
+// sift rules.  One wavefront owns one clip (offline) or one stream (realtime):
+// the flood is inherently serial per clip, the batch supplies the parallelism.
+// Wave-wide work (gradients, maxima / reseeds, thresholding) is lane-parallel.
+//
+// This file is compiled with -ffp-contract=off: every fp32 expression keeps
+// the reference's rounding sequence (no FMA contraction).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/acids_hip.h"
+
+namespace at_hip {
+
+struct HeapItem {
+  float key;  // -magnitude
+  int idx;    // row * F + col
+};
+
+// ---- heap primitives, single lane (utils/heapq.py) --------------------------
+__device__ __forceinline__ void h_siftdown(HeapItem* h, int startpos, int pos) {
+  HeapItem newitem = h[pos];
+  while (pos > startpos) {
+    const int parentpos = (pos - 1) >> 1;
+    const HeapItem parent = h[parentpos];
+    if (newitem.key < parent.key) {
+      h[pos] = parent;
+      pos = parentpos;
+      continue;
+    }
+    break;
+  }
+  h[pos] = newitem;
+}
+
+__device__ __forceinline__ void h_siftup(HeapItem* h, int endpos, int pos) {
+  const int startpos = pos;
+  const HeapItem newitem = h[pos];
+  int childpos = 2 * pos + 1;
+  while (childpos < endpos) {
+    const int rightpos = childpos + 1;
+    if (rightpos < endpos && !(h[childpos].key < h[rightpos].key)) childpos = rightpos;
+    h[pos] = h[childpos];
+    pos = childpos;
+    childpos = 2 * pos + 1;
+  }
+  h[pos] = newitem;
+  h_siftdown(h, startpos, pos);
+}
+
+__device__ __forceinline__ void h_push(HeapItem* h, int& n, float key, int idx) {
+  h[n].key = key;
+  h[n].idx = idx;
+  ++n;
+  h_siftdown(h, 0, n - 1);
+}
+
+__device__ __forceinline__ HeapItem h_pop(HeapItem* h, int& n) {
+  const HeapItem last = h[n - 1];
+  --n;
+  if (n > 0) {
+    const HeapItem ret = h[0];
+    h[0] = last;
+    h_siftup(h, n, 0);
+    return ret;
+  }
+  return last;
+}
+
+// ---- wave-wide (value, first index) arg-max --------------------------------
+__device__ __forceinline__ void wave_argmax(float& v, long long& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const long long oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) {
+      v = ov;
+      i = oi;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K13 offline: s = clamp(mag, eps); log; replicate-padded central differences
+// ---------------------------------------------------------------------------
+struct GradParams {
+  const float* mag;  // (B, T, F)
+  float* spec;       // (B, T, F) clamped work copy (may be null)
+  float* tgradw;
+  float* fgradw;
+  long long B;
+  int T, F, n_fft, hop;
+  float gamma, eps;
+};
+
+__global__ __launch_bounds__(256) void pghi_grad_offline_kernel(GradParams p) {
+  const float fmul = p.gamma / (float)((long long)p.hop * (long long)p.n_fft);
+  const float fstep = ((float)(2.0 * 3.14159265358979323846) * (float)p.hop) / (float)p.n_fft;
+  const float pi_f = (float)3.14159265358979323846;
+  const long long per = (long long)p.T * p.F;
+  const long long total = p.B * per;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / per;
+    const long long r = i - b * per;
+    const int t = (int)(r / p.F), k = (int)(r - (long long)t * p.F);
+    const float* m = p.mag + b * per;
+    const int tu = t + 1 < p.T ? t + 1 : p.T - 1, td = t > 0 ? t - 1 : 0;
+    const int kr = k + 1 < p.F ? k + 1 : p.F - 1, kl = k > 0 ? k - 1 : 0;
+    const float c = fmaxf(m[r], p.eps);
+    const float right = logf(fmaxf(m[(long long)t * p.F + kr], p.eps));
+    const float left = logf(fmaxf(m[(long long)t * p.F + kl], p.eps));
+    const float up = logf(fmaxf(m[(long long)tu * p.F + k], p.eps));
+    const float dn = logf(fmaxf(m[(long long)td * p.F + k], p.eps));
+    const float dxdw = (right - left) / 2.0f;
+    const float dxdt = (up - dn) / 2.0f;
+    p.fgradw[i] = dxdw / fmul + fstep * (float)k;
+    p.tgradw[i] = (-fmul) * dxdt + pi_f;
+    if (p.spec) p.spec[i] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K14 offline: one wave per clip
+// ---------------------------------------------------------------------------
+struct HgiParams {
+  float* spec;          // (B, T, F) clamped magnitudes, consumed (visited cells <- abstol)
+  const float* tgradw;  // (B, T, F)
+  const float* fgradw;
+  float* phase;         // (B, T, F) output
+  HeapItem* heap;       // (B, T*F + 2)
+  long long B;
+  int T, F;
+  float abstol, tol;
+  long long* npops;     // optional (B) number of pops per clip
+  int* order;           // optional (B, T*F) pop order (row*F+col), for the parity tests
+};
+
+// The reference rewrites every cell below max*tol to abstol up front
+// (dgt.py:177-178); here that threshold is applied when a cell is read.
+__device__ __forceinline__ bool live(float v, float abstol, float thr) { return v > abstol && !(v < thr); }
+
+// global (value, first row-major index) maximum over the live cells of one clip
+__device__ __forceinline__ void clip_argmax(const float* spec, long long n, float abstol, float thr, bool use_thr,
+                                            int lane, float& best, long long& besti) {
+  float v = -1.0f;
+  long long vi = n;
+  for (long long i = lane; i < n; i += 64) {
+    float s = spec[i];
+    if (use_thr && s < thr) s = abstol;
+    if (s > v) {
+      v = s;
+      vi = i;
+    }
+  }
+  wave_argmax(v, vi);
+  best = v;
+  besti = vi;
+}
+
+__global__ __launch_bounds__(64) void pghi_hgi_offline_kernel(HgiParams p) {
+  const long long b = blockIdx.x;
+  if (b >= p.B) return;
+  const int lane = threadIdx.x;
+  const int T = p.T, F = p.F;
+  const long long n = (long long)T * F;
+  float* spec = p.spec + b * n;
+  const float* tg = p.tgradw + b * n;
+  const float* fg = p.fgradw + b * n;
+  float* phase = p.phase + b * n;
+  HeapItem* heap = p.heap + b * (n + 2);
+  int* order = p.order ? p.order + b * n : nullptr;
+  const float abstol = p.abstol;
+
+  for (long long i = lane; i < n; i += 64) phase[i] = 0.0f;  // dgt.py:170
+
+  float max_val;
+  long long max_pos;
+  clip_argmax(spec, n, abstol, 0.f, false, lane, max_val, max_pos);  // :173-174
+  const float thr = max_val * p.tol;                                   // :177-178
+  long long npops = 0;
+  int hn = 0;
+  if (lane == 0) {
+    heap[0].key = -max_val;  // :175
+    heap[0].idx = (int)max_pos;
+    spec[max_pos] = abstol;  // :176
+  }
+  hn = 1;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+  while (max_val > abstol) {  // :179
+    if (lane == 0) {
+      while (hn > 0) {  // :180
+        const HeapItem it = h_pop(heap, hn);
+        if (order) order[npops] = it.idx;
+        ++npops;
+        const int c = it.idx;
+        const int col = c / F;      // frame
+        const int row = c - col * F;  // bin
+        const float pc = phase[c];
+        if (col < T - 1) {  // :188-194
+          const float s = spec[c + F];
+          if (live(s, abstol, thr)) {
+            phase[c + F] = pc + (fg[c] + fg[c + F]) / 2.0f;
+            h_push(heap, hn, -s, c + F);
+            spec[c + F] = abstol;
+          }
+        }
+        if (col > 0) {  // :195-201
+          const float s = spec[c - F];
+          if (live(s, abstol, thr)) {
+            phase[c - F] = pc - (fg[c] + fg[c - F]) / 2.0f;
+            h_push(heap, hn, -s, c - F);
+            spec[c - F] = abstol;
+          }
+        }
+        if (row < F - 1) {  // :202-208
+          const float s = spec[c + 1];
+          if (live(s, abstol, thr)) {
+            phase[c + 1] = pc + (tg[c] + tg[c + 1]) / 2.0f;
+            h_push(heap, hn, -s, c + 1);
+            spec[c + 1] = abstol;
+          }
+        }
+        if (row > 0) {  // :209-215
+          const float s = spec[c - 1];
+          if (live(s, abstol, thr)) {
+            phase[c - 1] = pc - (tg[c] + tg[c - 1]) / 2.0f;
+            h_push(heap, hn, -s, c - 1);
+            spec[c - 1] = abstol;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __threadfence_block();
+    // :216-219 reseed from the global max of what is left (lane-parallel scan)
+    clip_argmax(spec, n, abstol, thr, true, lane, max_val, max_pos);
+    if (lane == 0) {
+      heap[0].key = -max_val;
+      heap[0].idx = (int)max_pos;
+      spec[max_pos] = abstol;
+    }
+    hn = 1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  if (p.npops && lane == 0) p.npops[b] = npops;
+}
+
+// ---------------------------------------------------------------------------
+// realtime: gradients on the (R = n+2, F) stack [2 history frames ; n new frames]
+// (dgt.py:378-397).  The reference's uninitialised time-border rows are defined as 0.
+// ---------------------------------------------------------------------------
+struct RtParams {
+  const float* mag_hist;    // (S, 2, F)
+  const float* mag;         // (S, n, F)
+  const float* prev_phase;  // (S, F)
+  const float* noise;       // (S, n, F)
+  float* phase_out;         // (S, n, F)
+  float* spec;              // (S, R, F) work
+  float* hist;              // (S, R, F) work (untouched copy)
+  float* tgradw;            // (S, R, F) work
+  float* fgradw;            // (S, R, F) work
+  float* phase;             // (S, R, F) work
+  HeapItem* heap;           // (S, 4F + 8)
+  int S, n, F, n_fft, hop;
+  float gamma, tol, eps;
+};
+
+__device__ __forceinline__ float rt_mag(const RtParams& p, int s, int j, int k) {
+  const float v = (j < 2) ? p.mag_hist[((long long)s * 2 + j) * p.F + k] : p.mag[((long long)s * p.n + (j - 2)) * p.F + k];
+  return fmaxf(v, p.eps);
+}
+
+__global__ __launch_bounds__(256) void pghi_grad_rt_kernel(RtParams p) {
+  const float fmul = p.gamma / (float)((long long)p.hop * (long long)p.n_fft);
+  const float fstep = ((float)(2.0 * 3.14159265358979323846) * (float)p.hop) / (float)p.n_fft;
+  const float pi_f = (float)3.14159265358979323846;
+  const int R = p.n + 2;
+  const long long per = (long long)R * p.F;
+  const long long total = (long long)p.S * per;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)(i / per);
+    const long long r = i - (long long)s * per;
+    const int j = (int)(r / p.F), k = (int)(r - (long long)j * p.F);
+    const int kr = k + 1 < p.F ? k + 1 : p.F - 1, kl = k > 0 ? k - 1 : 0;
+    const float c = rt_mag(p, s, j, k);
+    const float right = logf(rt_mag(p, s, j, kr));
+    const float left = logf(rt_mag(p, s, j, kl));
+    const float nxt = (j + 1 < R) ? logf(rt_mag(p, s, j + 1, k)) : 0.0f;
+    const float prv = (j > 0) ? logf(rt_mag(p, s, j - 1, k)) : 0.0f;
+    const float dxdw = (right - left) / 2.0f;                          // :393
+    const float dxdt = (3.0f * nxt - 4.0f * logf(c) + prv) / 2.0f;     // :394
+    p.fgradw[i] = dxdw / fmul + fstep * (float)k;                      // :395
+    p.tgradw[i] = (-fmul) * dxdt + pi_f;                               // :396
+    p.spec[i] = c;
+    p.hist[i] = c;
+  }
+}
+
+// dgt.py:399-466, one wave per stream
+__global__ __launch_bounds__(64) void pghi_hgi_rt_kernel(RtParams p) {
+  const int s = blockIdx.x;
+  if (s >= p.S) return;
+  const int lane = threadIdx.x;
+  const int F = p.F, R = p.n + 2;
+  const long long n = (long long)R * F;
+  float* spec = p.spec + (long long)s * n;
+  const float* hist = p.hist + (long long)s * n;
+  const float* tgw = p.tgradw + (long long)s * n;
+  const float* fgw = p.fgradw + (long long)s * n;
+  float* phase = p.phase + (long long)s * n;
+  HeapItem* heap = p.heap + (long long)s * (4LL * F + 8);
+
+  // :400 abstol = clamp(tol * max(spec), eps)
+  float smax = -1.0f;
+  for (long long i = lane; i < n; i += 64) smax = fmaxf(smax, spec[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+  float abstol = p.tol * smax;
+  if (abstol < p.eps) abstol = p.eps;
+
+  // :402-405 initial phase: row 0 zeros, row 1 previous phase, rows >= 2 zero above abstol else noise
+  for (long long i = lane; i < n; i += 64) {
+    float v;
+    if (i < F) v = 0.0f;
+    else if (i < 2LL * F) v = p.prev_phase[(long long)s * F + (i - F)];
+    else v = (spec[i] > abstol) ? 0.0f : p.noise[(long long)s * p.n * F + (i - 2LL * F)];
+    phase[i] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __threadfence_block();
+
+  // the reference front-pads the gradients with two zero rows (:408-410): "row r" there is row r-2 here
+#define TG(r, k) ((r) >= 2 ? tgw[(long long)((r)-2) * F + (k)] : 0.0f)
+#define FG(r, k) ((r) >= 2 ? fgw[(long long)((r)-2) * F + (k)] : 0.0f)
+  for (int f = 2; f < R; ++f) {  // :413
+    float* row = spec + (long long)f * F;
+    float max_val = -1.0f;
+    long long max_k = F;
+    for (int k = lane; k < F; k += 64) {
+      const float v = row[k];
+      if (v > max_val) {
+        max_val = v;
+        max_k = k;
+      }
+    }
+    wave_argmax(max_val, max_k);
+    if (max_val <= abstol) continue;  // :416-417
+    if (lane == 0) {
+      int hn = 0;
+      heap[0].key = -max_val;  // :427 the seed is NOT marked visited
+      heap[0].idx = f * F + (int)max_k;
+      hn = 1;
+      for (int k = 0; k < F; ++k) {  // :428-430
+        const float hv = hist[(long long)(f - 1) * F + k];
+        if (hv > abstol) h_push(heap, hn, -hv, (f - 1) * F + k);
+      }
+      while (max_val > abstol) {  // :433
+        while (hn > 0) {
+          const HeapItem it = h_pop(heap, hn);
+          const int r = it.idx / F, k = it.idx - r * F;
+          if (r == f - 1) {  // :436-443 propagate in time
+            const float sv = row[k];
+            if (sv > abstol) {
+              phase[(long long)f * F + k] = phase[(long long)(f - 1) * F + k] + 0.5f * (TG(f - 1, k) + TG(f, k));
+              h_push(heap, hn, -sv, f * F + k);
+              row[k] = abstol;
+            }
+          }
+          if (r == f) {  // :444-460 propagate in frequency
+            if (k + 1 < F) {
+              const float sv = row[k + 1];
+              if (sv > abstol) {
+                phase[(long long)f * F + k + 1] = phase[(long long)f * F + k] + 0.5f * (FG(f, k) + FG(f, k + 1));
+                h_push(heap, hn, -sv, f * F + k + 1);
+                row[k + 1] = abstol;
+              }
+            }
+            if (k - 1 > 0) {  // bin 0 is never reached downward (:453)
+              const float sv = row[k - 1];
+              if (sv > abstol) {
+                phase[(long long)f * F + k - 1] = phase[(long long)f * F + k] - 0.5f * (FG(f, k) + FG(f, k - 1));
+                h_push(heap, hn, -sv, f * F + k - 1);
+                row[k - 1] = abstol;
+              }
+            }
+          }
+        }
+        // :461-465 reseed inside the frame
+        max_val = row[0];
+        int mk = 0;
+        for (int k = 1; k < F; ++k)
+          if (row[k] > max_val) {
+            max_val = row[k];
+            mk = k;
+          }
+        h_push(heap, hn, -max_val, f * F + mk);
+        row[mk] = abstol;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __threadfence_block();
+  }
+#undef TG
+#undef FG
+  for (long long i = lane; i < (long long)p.n * F; i += 64) p.phase_out[(long long)s * p.n * F + i] = phase[2LL * F + i];
+}
+
+// x = mag * exp(i phase): refresh the PGHI history (|x[-2:]|, angle(x[-1]))   dgt.py:325-336
+struct RtUpdParams {
+  const float* mag;       // (S, n, F)
+  const float* phase;     // (S, n, F)
+  const float* hist_in;   // (S, 2, F)
+  float* hist_out;        // (S, 2, F)
+  float* phase_out;       // (S, F)
+  int S, n, F;
+};
+
+__global__ __launch_bounds__(256) void rt_update_kernel(RtUpdParams p) {
+  const long long total = (long long)p.S * p.F;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)(i / p.F), k = (int)(i - (long long)s * p.F);
+    const long long last = ((long long)s * p.n + (p.n - 1)) * p.F + k;
+    float sn, cs;
+    sincosf(p.phase[last], &sn, &cs);
+    const float re = p.mag[last] * cs, im = p.mag[last] * sn;
+    float prev;
+    if (p.n > 1) {
+      const long long l2 = last - p.F;
+      float s2, c2;
+      sincosf(p.phase[l2], &s2, &c2);
+      prev = hypotf(p.mag[l2] * c2, p.mag[l2] * s2);
+    } else {
+      prev = p.hist_in[((long long)s * 2 + 1) * p.F + k];
+    }
+    p.hist_out[((long long)s * 2) * p.F + k] = prev;
+    p.hist_out[((long long)s * 2 + 1) * p.F + k] = hypotf(re, im);
+    p.phase_out[i] = atan2f(im, re);
+  }
+}
+
+static inline unsigned grid1d(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace at_hip
+
+using namespace at_hip;
+
+extern "C" {
+
+int at_pghi_gradients(const float* mag, int64_t B, int T, int F, float gamma, int n_fft, int hop, float eps,
+                      float* tgradw, float* fgradw, float* spec_or_null, void* stream) {
+  if (B < 0 || T <= 0 || F <= 0 || n_fft <= 0 || hop <= 0) return AT_EINVAL;
+  if (B == 0) return AT_OK;
+  if (!mag || !tgradw || !fgradw) return AT_EINVAL;
+  GradParams p = {mag, spec_or_null, tgradw, fgradw, (long long)B, T, F, n_fft, hop, gamma, eps};
+  hipLaunchKernelGGL(pghi_grad_offline_kernel, dim3(grid1d((long long)B * T * F)), dim3(256), 0, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+size_t at_pghi_offline_workspace_bytes(int64_t B, int T, int F) {
+  const size_t n = (size_t)T * (size_t)F;
+  // spec + tgradw + fgradw (fp32) + heap (8 B entries, n + 2)
+  return (size_t)B * (3 * n * sizeof(float) + (n + 2) * sizeof(HeapItem)) + 256;
+}
+
+int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int n_fft, int hop, float tol, float abstol,
+                    float* phase, void* workspace, size_t workspace_bytes, int64_t* npops_or_null,
+                    int32_t* order_or_null, void* stream) {
+  if (B < 0 || T <= 0 || F <= 0 || n_fft <= 0 || hop <= 0) return AT_EINVAL;
+  if (B == 0) return AT_OK;
+  if (!mag || !phase) return AT_EINVAL;
+  if ((long long)T * F > 0x7ffffff0LL) return AT_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < at_pghi_offline_workspace_bytes(B, T, F)) return AT_EWORKSPACE;
+  const size_t n = (size_t)T * (size_t)F;
+  float* spec = (float*)workspace;
+  float* tg = spec + (size_t)B * n;
+  float* fg = tg + (size_t)B * n;
+  uintptr_t hp = ((uintptr_t)(fg + (size_t)B * n) + 15) & ~(uintptr_t)15;
+  HeapItem* heap = (HeapItem*)hp;
+  hipStream_t s = (hipStream_t)stream;
+  GradParams g = {mag, spec, tg, fg, (long long)B, T, F, n_fft, hop, gamma, abstol};
+  hipLaunchKernelGGL(pghi_grad_offline_kernel, dim3(grid1d((long long)B * T * F)), dim3(256), 0, s, g);
+  HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, order_or_null};
+  hipLaunchKernelGGL(pghi_hgi_offline_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+size_t at_pghi_rt_workspace_bytes(int S, int n, int F) {
+  const size_t per = (size_t)(n + 2) * (size_t)F;
+  return (size_t)S * (5 * per * sizeof(float) + (4 * (size_t)F + 8) * sizeof(HeapItem)) + 256;
+}
+
+int at_pghi_realtime(const float* mag_hist, const float* mag, const float* prev_phase, const float* noise, int S, int n,
+                     int F, float gamma, int n_fft, int hop, float tol, float eps, float* phase, float* tgradw_or_null,
+                     float* fgradw_or_null, void* workspace, size_t workspace_bytes, void* stream) {
+  if (S < 0 || n <= 0 || F <= 0 || n_fft <= 0 || hop <= 0) return AT_EINVAL;
+  if (S == 0) return AT_OK;
+  if (!mag_hist || !mag || !prev_phase || !noise || !phase) return AT_EINVAL;
+  if (!workspace || workspace_bytes < at_pghi_rt_workspace_bytes(S, n, F)) return AT_EWORKSPACE;
+  const size_t per = (size_t)(n + 2) * (size_t)F;
+  float* w = (float*)workspace;
+  RtParams p;
+  p.mag_hist = mag_hist; p.mag = mag; p.prev_phase = prev_phase; p.noise = noise; p.phase_out = phase;
+  p.spec = w; p.hist = w + (size_t)S * per;
+  p.tgradw = tgradw_or_null ? tgradw_or_null : w + 2 * (size_t)S * per;
+  p.fgradw = fgradw_or_null ? fgradw_or_null : w + 3 * (size_t)S * per;
+  p.phase = w + 4 * (size_t)S * per;
+  uintptr_t hp = ((uintptr_t)(w + 5 * (size_t)S * per) + 15) & ~(uintptr_t)15;
+  p.heap = (HeapItem*)hp;
+  p.S = S; p.n = n; p.F = F; p.n_fft = n_fft; p.hop = hop; p.gamma = gamma; p.tol = tol; p.eps = eps;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(pghi_grad_rt_kernel, dim3(grid1d((long long)S * per)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(pghi_hgi_rt_kernel, dim3((unsigned)S), dim3(64), 0, s, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+int at_rt_update_buffers(const float* mag, const float* phase, int S, int n, int F, const float* hist_in,
+                         float* hist_out, float* phase_out, void* stream) {
+  if (S < 0 || n <= 0 || F <= 0) return AT_EINVAL;
+  if (S == 0) return AT_OK;
+  if (!mag || !phase || !hist_in || !hist_out || !phase_out) return AT_EINVAL;
+  RtUpdParams p = {mag, phase, hist_in, hist_out, phase_out, S, n, F};
+  hipLaunchKernelGGL(rt_update_kernel, dim3(grid1d((long long)S * F)), dim3(256), 0, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+}  // extern "C"

@@ -203,3 +203,68 @@ def mel_forward_real(x, mat, offset=None, scale=None, channel_major_T=0):
     check(lib().at_mel_project(ptr(x), 2, rows, K, K, ptr(mat), N, N, 0, 0, ptr(offset), ptr(scale), 0.0, ptr(out), N,
                                channel_major_T, stream_ptr()), "at_mel_project")
     return out
+
+
+def _workspace(nbytes, device):
+    return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=device)
+
+
+def pghi_gradients(mag, gamma, n_fft, hop, eps=1.1920929e-07):
+    """(B, T, F) magnitudes -> (tgradw, fgradw), each (B, T, F)."""
+    require_device(mag)
+    mag = _f32c(mag)
+    B, T, F = mag.shape
+    tg = torch.empty_like(mag)
+    fg = torch.empty_like(mag)
+    check(lib().at_pghi_gradients(ptr(mag), B, T, F, gamma, n_fft, hop, eps, ptr(tg), ptr(fg), ptr(None),
+                                  stream_ptr()), "at_pghi_gradients")
+    return tg, fg
+
+
+def pghi_offline(mag, gamma, n_fft, hop, tol, eps=1.1920929e-07, debug=False):
+    """(B, T, F) magnitudes -> phase (B, T, F); debug=True also returns (npops, order)."""
+    require_device(mag)
+    mag = _f32c(mag)
+    B, T, F = mag.shape
+    phase = torch.empty_like(mag)
+    wsb = lib().at_pghi_offline_workspace_bytes(B, T, F)
+    ws = _workspace(wsb, mag.device)
+    npops = torch.zeros(B, dtype=torch.int64, device=mag.device) if debug else None
+    order = torch.full((B, T * F), -1, dtype=torch.int32, device=mag.device) if debug else None
+    check(lib().at_pghi_offline(ptr(mag), B, T, F, gamma, n_fft, hop, tol, eps, ptr(phase), ptr(ws), wsb, ptr(npops),
+                                ptr(order), stream_ptr()), "at_pghi_offline")
+    return (phase, npops, order) if debug else phase
+
+
+def pghi_realtime(mag_hist, mag, prev_phase, noise, gamma, n_fft, hop, tol, eps=1.1920929e-07, debug=False):
+    """streaming PGHI for S streams: (S,2,F), (S,n,F), (S,F), (S,n,F) -> phase (S,n,F)."""
+    require_device(mag, mag_hist, prev_phase, noise)
+    mag_hist, mag, prev_phase, noise = _f32c(mag_hist), _f32c(mag), _f32c(prev_phase), _f32c(noise)
+    S, n, F = mag.shape
+    phase = torch.empty_like(mag)
+    wsb = lib().at_pghi_rt_workspace_bytes(S, n, F)
+    ws = _workspace(wsb, mag.device)
+    tg = torch.empty((S, n + 2, F), dtype=torch.float32, device=mag.device) if debug else None
+    fg = torch.empty((S, n + 2, F), dtype=torch.float32, device=mag.device) if debug else None
+    check(lib().at_pghi_realtime(ptr(mag_hist), ptr(mag), ptr(prev_phase), ptr(noise), S, n, F, gamma, n_fft, hop, tol,
+                                 eps, ptr(phase), ptr(tg), ptr(fg), ptr(ws), wsb, stream_ptr()), "at_pghi_realtime")
+    return (phase, tg, fg) if debug else phase
+
+
+def rt_polar_irfft_update(mag, phase, inv_window, n_fft, mag_hist):
+    """x = mag*exp(i*phase): windowed irfft frames (..., n, n_fft) plus the refreshed PGHI
+    history buffers (|x[-2:]|, angle(x[-1]))."""
+    require_device(mag, phase, inv_window, mag_hist)
+    mag, phase = _f32c(mag), _f32c(phase)
+    frames = irfft_frames(None, inv_window, n_fft, mag=mag, phase=phase)
+    lead = mag.shape[:-2]
+    n, F = mag.shape[-2], mag.shape[-1]
+    S = 1
+    for d in lead:
+        S *= d
+    hist_in = _f32c(mag_hist)
+    hist_out = torch.empty(tuple(lead) + (2, F), dtype=torch.float32, device=mag.device)
+    ph_out = torch.empty(tuple(lead) + (F,), dtype=torch.float32, device=mag.device)
+    check(lib().at_rt_update_buffers(ptr(mag), ptr(phase), S, n, F, ptr(hist_in), ptr(hist_out), ptr(ph_out),
+                                     stream_ptr()), "at_rt_update_buffers")
+    return frames, hist_out, ph_out

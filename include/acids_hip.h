@@ -108,6 +108,40 @@ int at_stats(const void *A, int a_kind, int64_t n, int contrast, float eps, doub
 int at_affine(const float *x, int64_t n, const float *offset, const float *scale, int inverse, float *out,
               void *stream);
 
+/* ---- K13/K14: PGHI --------------------------------------------------------- */
+/* DGT.modgabphasegrad (dgt.py:222-236) on B clamped-on-the-fly (T,F) magnitude
+ * arrays: tgradw, fgradw (B,T,F).  spec_or_null receives clamp(mag, eps). */
+int at_pghi_gradients(const float *mag, int64_t B, int T, int F, float gamma, int n_fft, int hop, float eps,
+                      float *tgradw, float *fgradw, float *spec_or_null, void *stream);
+
+size_t at_pghi_offline_workspace_bytes(int64_t B, int T, int F);
+
+/* DGT.pghi + perform_hgi for every clip of a batch (dgt.py:137-141, 156-220) with
+ * the binary-heap order of utils/heapq.py:9-59.  abstol is both the clamp floor
+ * and the "visited" marker (the reference passes eps for both, dgt.py:157-162).
+ * phase: (B,T,F).  npops_or_null: (B) pops per clip.  order_or_null: (B, T*F)
+ * row*F+col of every pop in order (parity tests). */
+int at_pghi_offline(const float *mag, int64_t B, int T, int F, float gamma, int n_fft, int hop, float tol,
+                    float abstol, float *phase, void *workspace, size_t workspace_bytes, int64_t *npops_or_null,
+                    int32_t *order_or_null, void *stream);
+
+size_t at_pghi_rt_workspace_bytes(int S, int n, int F);
+
+/* RealtimeDGT.pghi (dgt.py:338-354, 378-466) for S streams: mag_hist (S,2,F),
+ * mag (S,n,F), prev_phase (S,F), noise (S,n,F) standard-normal draws for the bins
+ * at or below the tolerance (dgt.py:404-405) -> phase (S,n,F).  The time-border
+ * rows the reference leaves uninitialised (dgt.py:388-394) are defined as 0.
+ * tgradw/fgradw_or_null: optional (S,n+2,F) outputs. */
+int at_pghi_realtime(const float *mag_hist, const float *mag, const float *prev_phase, const float *noise, int S,
+                     int n, int F, float gamma, int n_fft, int hop, float tol, float eps, float *phase,
+                     float *tgradw_or_null, float *fgradw_or_null, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
+/* RealtimeDGT.update_buffers (dgt.py:330-336) for x = mag*exp(i*phase):
+ * hist_out = |x[-2:]| (or [hist_in[1], |x[-1]|] when n == 1), phase_out = angle(x[-1]). */
+int at_rt_update_buffers(const float *mag, const float *phase, int S, int n, int F, const float *hist_in,
+                         float *hist_out, float *phase_out, void *stream);
+
 /* ---- pointwise ----------------------------------------------------------- */
 /* x.angle() on n complex64 values: the phase_buffer of stft.py:103 / dgt.py:69,
  * and hgi_phase_buffer of dgt.py:336. */
