@@ -42,6 +42,12 @@ _SIGNATURES = {
     "at_pghi_realtime": [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_flt, c_int, c_int, c_flt, c_flt, c_f, c_f, c_f,
                          c_f, c_sz, c_f],
     "at_rt_update_buffers": [c_f, c_f, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
+    "at_oadd_forward": [c_f, c_f, c_int, c_i64, c_int, c_i64, c_f, c_f, c_f],
+    "at_oadd_invert": [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
+    "at_mulaw_encode": [c_f, c_i64, c_int, c_f, c_f],
+    "at_mulaw_decode": [c_f, c_f, c_i64, c_int, c_f, c_f],
+    "at_onehot": [c_f, c_i64, c_int, c_i64, c_f, c_f],
+    "at_argmax_last": [c_f, c_f, c_i64, c_int, c_f, c_f],
 }
 _RESTYPES = {"at_error_string": ctypes.c_char_p, "at_istft_workspace_bytes": c_sz, "at_stats_workspace_bytes": c_sz,
              "at_pghi_offline_workspace_bytes": c_sz, "at_pghi_rt_workspace_bytes": c_sz}

@@ -102,6 +102,47 @@ __global__ void affine_kernel(const float* __restrict__ x, long long n, const fl
     out[i] = inverse ? __fadd_rn(__fmul_rn(x[i], sc), off) : (x[i] - off) / sc;
 }
 
+// ---------------------------------------------------------------------------
+// OverlapAdd streaming state (reference transforms/oadd.py)
+//   forward :69-74, 33-42  buf = [history | chunk | zero pad]; history <- chunk[-keep:]      (K6)
+//   invert  :90-104        rec = [tail | 0] + sum_i frames[i] shifted by i*hop;
+//                          out = rec[:-keep] / gain; tail <- rec[-keep:]                      (K7)
+// ---------------------------------------------------------------------------
+__global__ void oadd_forward_kernel(const float* __restrict__ x, const float* __restrict__ hist_in, int S, long long C,
+                                    int keep, long long buf_len, float* __restrict__ buf, float* __restrict__ hist_out) {
+  const long long total = (long long)S * buf_len;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i / buf_len, p = i - s * buf_len;
+    float v = 0.f;
+    if (p < keep) v = hist_in ? hist_in[s * keep + p] : 0.f;
+    else if (p < keep + C) v = x[s * C + (p - keep)];
+    buf[i] = v;
+    if (p >= C && p < C + keep) hist_out[s * keep + (p - C)] = v;  // last `keep` samples of [hist | chunk]
+  }
+}
+
+__global__ void oadd_invert_kernel(const float* __restrict__ frames, const float* __restrict__ tail_in, int S, int n,
+                                   int n_fft, int hop, int keep, const float* gain, float* __restrict__ out,
+                                   float* __restrict__ tail_out) {
+  const long long rec_len = (long long)(n - 1) * hop + n_fft;
+  const long long out_len = rec_len - keep;
+  const long long total = (long long)S * rec_len;
+  const float g = *gain;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i / rec_len, p = i - s * rec_len;
+    float acc = (tail_in && p < keep) ? tail_in[s * keep + p] : 0.f;
+    long long t_hi = p / hop;
+    if (t_hi > n - 1) t_hi = n - 1;
+    long long t_lo = (p >= n_fft) ? (p - n_fft + hop) / hop : 0;
+    for (long long t = t_lo; t <= t_hi; ++t) {  // ascending frame order, like the reference's += loop
+      const long long o = p - t * hop;
+      if (o >= 0 && o < n_fft) acc += frames[(s * n + t) * n_fft + o];
+    }
+    if (p < out_len) out[s * out_len + p] = acc / g;
+    else tail_out[s * keep + (p - out_len)] = acc;
+  }
+}
+
 static inline unsigned grid_for(long long n, int block) {
   long long b = (n + block - 1) / block;
   if (b > 256 * 8) b = 256 * 8;  // grid-stride above 8 blocks per CU
@@ -151,6 +192,30 @@ int at_affine(const float* x, int64_t n, const float* offset, const float* scale
   if (!x || !offset || !scale || !out) return AT_EINVAL;
   hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, offset,
                      scale, inverse, out);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+
+int at_oadd_forward(const float* x, const float* hist_in_or_null, int S, int64_t C, int keep, int64_t buf_len,
+                    float* buf, float* hist_out, void* stream) {
+  if (S < 0 || C <= 0 || keep < 0 || buf_len < keep + C) return AT_EINVAL;
+  if (C < keep) return AT_EINVAL;  // the reference's history slice silently shortens here (oadd.py:41)
+  if (S == 0) return AT_OK;
+  if (!x || !buf || !hist_out) return AT_EINVAL;
+  hipLaunchKernelGGL(oadd_forward_kernel, dim3(grid_for((long long)S * buf_len, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     hist_in_or_null, S, (long long)C, keep, (long long)buf_len, buf, hist_out);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+int at_oadd_invert(const float* frames, const float* tail_in_or_null, int S, int n, int n_fft, int hop, int keep,
+                   const float* gain, float* out, float* tail_out, void* stream) {
+  if (S < 0 || n <= 0 || n_fft <= 0 || hop <= 0 || keep < 0) return AT_EINVAL;
+  if ((long long)(n - 1) * hop + n_fft < keep) return AT_EINVAL;
+  if (S == 0) return AT_OK;
+  if (!frames || !gain || !out || !tail_out) return AT_EINVAL;
+  const long long rec_len = (long long)(n - 1) * hop + n_fft;
+  hipLaunchKernelGGL(oadd_invert_kernel, dim3(grid_for((long long)S * rec_len, 256)), dim3(256), 0, (hipStream_t)stream,
+                     frames, tail_in_or_null, S, n, n_fft, hop, keep, gain, out, tail_out);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 

@@ -268,3 +268,86 @@ def rt_polar_irfft_update(mag, phase, inv_window, n_fft, mag_hist):
     check(lib().at_rt_update_buffers(ptr(mag), ptr(phase), S, n, F, ptr(hist_in), ptr(hist_out), ptr(ph_out),
                                      stream_ptr()), "at_rt_update_buffers")
     return frames, hist_out, ph_out
+
+
+def oadd_forward(x2d, hist, keep, n_fft, hop):
+    """x2d (S, C), hist (S, keep) or None -> (buf (S, buf_len), new_hist (S, keep), n_frames)."""
+    from .utils.misc import n_frames
+    require_device(x2d)
+    x2d = _f32c(x2d)
+    S, C = x2d.shape
+    if C < keep:
+        raise ValueError("OverlapAdd needs chunks of at least %d samples (got %d)" % (keep, C))
+    total = keep + C
+    nw = n_frames(total, n_fft, hop)
+    buf_len = max(total, nw * hop + n_fft)
+    buf = torch.empty((S, buf_len), dtype=torch.float32, device=x2d.device)
+    new_hist = torch.empty((S, keep), dtype=torch.float32, device=x2d.device)
+    check(lib().at_oadd_forward(ptr(x2d), ptr(hist), S, C, keep, buf_len, ptr(buf), ptr(new_hist), stream_ptr()),
+          "at_oadd_forward")
+    return buf, new_hist, nw
+
+
+def oadd_invert(frames3d, tail, n_fft, hop, keep, gain):
+    """frames (S, n, n_fft), tail (S, keep) or None -> (out (S, (n-1)*hop+n_fft-keep), new_tail (S, keep))."""
+    require_device(frames3d, gain)
+    frames3d = _f32c(frames3d)
+    S, n, _ = frames3d.shape
+    out_len = (n - 1) * hop + n_fft - keep
+    out = torch.empty((S, out_len), dtype=torch.float32, device=frames3d.device)
+    new_tail = torch.empty((S, keep), dtype=torch.float32, device=frames3d.device)
+    check(lib().at_oadd_invert(ptr(frames3d), ptr(tail), S, n, n_fft, hop, keep, ptr(gain), ptr(out), ptr(new_tail),
+                               stream_ptr()), "at_oadd_invert")
+    return out, new_tail
+
+
+def mulaw_encode(x, channels):
+    require_device(x)
+    if not x.is_floating_point():
+        raise TypeError("The input Tensor must be of floating type.")
+    x = _f32c(x)
+    out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+    check(lib().at_mulaw_encode(ptr(x), x.numel(), channels, ptr(out), stream_ptr()), "at_mulaw_encode")
+    return out
+
+
+def mulaw_decode(codes, channels):
+    require_device(codes)
+    codes = codes if codes.is_contiguous() else codes.contiguous()
+    ci = cf = None
+    if codes.is_floating_point():
+        cf = _f32c(codes)
+    else:
+        ci = codes.long()
+    out = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+    check(lib().at_mulaw_decode(ptr(ci), ptr(cf), codes.numel(), channels, ptr(out), stream_ptr()), "at_mulaw_decode")
+    return out
+
+
+def onehot(x, classes, channel_major=False):
+    require_device(x)
+    if x.dtype != torch.int64:
+        raise RuntimeError("one_hot is only applicable to index tensor of type LongTensor.")
+    x = x if x.is_contiguous() else x.contiguous()
+    if channel_major:
+        inner = x.shape[-1]
+        out = torch.empty(x.shape[:-1] + (classes, inner), dtype=torch.int64, device=x.device)
+    else:
+        inner = 0
+        out = torch.empty(x.shape + (classes,), dtype=torch.int64, device=x.device)
+    check(lib().at_onehot(ptr(x), x.numel(), classes, inner, ptr(out), stream_ptr()), "at_onehot")
+    return out
+
+
+def argmax_last(x):
+    require_device(x)
+    x = x if x.is_contiguous() else x.contiguous()
+    xi = xf = None
+    if x.is_floating_point():
+        xf = _f32c(x)
+    else:
+        xi = x.long()
+    cols = x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    check(lib().at_argmax_last(ptr(xi), ptr(xf), x.numel() // cols, cols, ptr(out), stream_ptr()), "at_argmax_last")
+    return out

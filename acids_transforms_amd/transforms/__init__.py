@@ -5,7 +5,10 @@ from .dgt import DGT, RealtimeDGT
 from .norm import Normalize
 from .spectral_repr import Magnitude
 from .mel import MFCC
+from .oadd import OverlapAdd
+from .raw import MuLaw
+from .misc import OneHot
 
 __all__ = ["AudioTransform", "ComposeAudioTransform", "NotInvertibleError", "InversionEnumType",
            "apply_transform_to_list", "apply_invert_transform_to_list", "STFT", "RealtimeSTFT", "DGT", "RealtimeDGT",
-           "Normalize", "Magnitude", "MFCC"]
+           "Normalize", "Magnitude", "MFCC", "OverlapAdd", "MuLaw", "OneHot"]

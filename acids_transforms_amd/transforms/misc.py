@@ -1,0 +1,37 @@
+"""OneHot (reference transforms/misc.py:156-213): F.one_hot forward, argmax inverse."""
+import torch
+
+from .. import ops
+from .base import AudioTransform, InversionEnumType
+
+__all__ = ["OneHot"]
+
+
+class OneHot(AudioTransform):
+    scriptable = False
+    invertible = True
+
+    @property
+    def needs_scaling(self):
+        return self.n_classes == -1
+
+    def __init__(self, sr=44100, dtype=torch.long, n_classes: int = -1):
+        super().__init__(sr)
+        self.dtype = dtype
+        self.n_classes = n_classes
+
+    def __repr__(self):
+        return "OneHot(n_classes=%s)" % self.n_classes
+
+    def scale_data(self, x: torch.Tensor) -> None:
+        self.n_classes = int(x.max()) + 1
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n = self.n_classes
+        if n == -1:     # F.one_hot infers the class count from the data
+            n = int(x.max()) + 1
+        return ops.onehot(x, n)
+
+    def invert(self, x_onehot: torch.Tensor, inversion_mode: InversionEnumType = None,
+               tolerance: float = 1.e-4) -> torch.Tensor:
+        return ops.argmax_last(x_onehot)

@@ -147,6 +147,29 @@ int at_rt_update_buffers(const float *mag, const float *phase, int S, int n, int
  * and hgi_phase_buffer of dgt.py:336. */
 int at_angle(const float *x_complex, int64_t n, float *out, void *stream);
 
+/* ---- K6/K7: OverlapAdd streaming framer / overlap-add ---------------------- */
+/* OverlapAdd.forward (oadd.py:69-74, 33-42): buf (S, buf_len) = [history | chunk | 0...],
+ * hist_out = last `keep` samples of [history | chunk].  The caller takes the
+ * (S, n, n_fft) frames as a strided view of buf (utils/misc.py:148-165).  C >= keep. */
+int at_oadd_forward(const float *x, const float *hist_in_or_null, int S, int64_t C, int keep, int64_t buf_len,
+                    float *buf, float *hist_out, void *stream);
+/* OverlapAdd.invert (oadd.py:90-104): frames (S, n, n_fft) + carried tail (S, keep)
+ * -> out (S, (n-1)*hop + n_fft - keep) / gain, tail_out (S, keep) undivided. */
+int at_oadd_invert(const float *frames, const float *tail_in_or_null, int S, int n, int n_fft, int hop, int keep,
+                   const float *gain, float *out, float *tail_out, void *stream);
+
+/* ---- K16: integer transforms -------------------------------------------------- */
+/* torchaudio MuLawEncoding / MuLawDecoding as used by MuLaw (raw.py:282-283, 316):
+ * codes int64 in [0, channels). */
+int at_mulaw_encode(const float *x, int64_t n, int channels, int64_t *codes, void *stream);
+int at_mulaw_decode(const int64_t *codes_i64, const float *codes_f32, int64_t n, int channels, float *x,
+                    void *stream);
+/* F.one_hot(x, classes) (misc.py:183-185, raw.py:288-291): out (n, classes) int64, or with
+ * channel_major_inner = t > 0 the transposed (n/t, classes, t) layout of raw.py:289-290. */
+int at_onehot(const int64_t *x, int64_t n, int classes, int64_t channel_major_inner, int64_t *out, void *stream);
+/* Tensor.argmax(-1) (misc.py:188-189): first index of the row maximum. */
+int at_argmax_last(const int64_t *x_i64, const float *x_f32, int64_t rows, int cols, int64_t *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

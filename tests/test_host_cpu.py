@@ -1,0 +1,139 @@
+"""CPU-only checks: host-side logic of the drop-in modules against the reference's
+constants (goldens), the C ABI surface, and the product/oracle separation."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import acids_transforms_amd as A
+from acids_transforms_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_windows_gammas_gain_match_reference(golden):
+    g = golden("g1_constants")
+    for (n, h) in [(1024, 256), (512, 128), (128, 32), (32, 8), (2048, 512), (64, 16)]:
+        k = "%d_%d" % (n, h)
+        s, d, r = A.STFT(n_fft=n, hop_length=h), A.DGT(n_fft=n, hop_length=h), A.RealtimeDGT(n_fft=n, hop_length=h)
+        assert np.array_equal(s.window[:n].numpy(), g["hann_" + k]) and float(s.window[n:].abs().sum()) == 0
+        assert np.array_equal(s.inv_window[:n].numpy(), g["hann_" + k])
+        assert np.array_equal(d.window[:n].numpy(), g["gauss_" + k])
+        assert np.allclose(d.inv_window[:n].numpy(), g["dual_" + k], rtol=2e-7, atol=0)
+        assert np.array_equal(s.gamma.numpy(), g["gamma_stft_" + k])
+        assert np.array_equal(d.gamma.numpy(), g["gamma_dgt_" + k])
+        assert np.array_equal(r.gamma.numpy(), g["gamma_rt_" + k])
+        assert float(A.OverlapAdd(n, h).gain_compensation) == float(g["oadd_gain_" + k])
+        assert s.n_fft.shape == (1,) and s.n_fft.dtype == torch.int64 and int(s.hop_length) == h
+    assert np.float32(A.DGT().eps) == g["eps"] and np.float32(A.DGT().tolerance) == g["tolerance"]
+
+
+def test_state_dict_keys_match_reference(golden):
+    g = golden("g1_constants")
+    assert sorted(A.STFT().state_dict().keys()) == list(g["stft_state_keys"])
+    assert sorted(A.DGT().state_dict().keys()) == list(g["dgt_state_keys"])
+    assert sorted(A.RealtimeDGT().state_dict().keys()) == list(g["rtdgt_state_keys"])
+    m = A.Magnitude()
+    assert sorted(m.state_dict().keys()) == ["eps", "inverse_mel_bank", "mel_bank", "norm.offset", "norm.scale"]
+    assert m.mel_bank.shape == (1, 513, 513) and m.inverse_mel_bank.shape == (1, 513, 513)
+    d2 = A.DGT(n_fft=512, hop_length=128)
+    d2.load_state_dict(A.DGT().state_dict())             # a saved state re-targets n_fft / hop
+    assert d2.ratio == 256 and d2._n_fft == 1024
+    rt = A.RealtimeDGT(batch_size=[3, 2])
+    assert rt.hgi_mag_buffer.shape == (3, 2, 2, 513) and rt.hgi_phase_buffer.shape == (3, 2, 513)
+    rt.reset([5])
+    assert rt.hgi_mag_buffer.shape == (5, 2, 513) and rt.get_batch_size() == [5]
+
+
+def test_api_surface_and_errors():
+    s = A.STFT()
+    assert s.get_inversion_modes() == ["griffin_lim", "keep_input", "random", "sinebank"]
+    assert A.DGT.get_inversion_modes() == ["pghi", "griffin_lim", "random", "keep_input", "sinebank"]
+    assert A.RealtimeDGT.get_inversion_modes() == ["random", "pghi", "keep_input", "sinebank"]
+    assert A.RealtimeSTFT.get_inversion_modes() == ["keep_input", "random", "sinebank"]
+    assert s.ratio == 256 and s.invertible and not s.needs_scaling and s.inversion_mode == "griffin_lim"
+    assert A.DGT().inversion_mode == "pghi" and isinstance(A.DGT().realtime(), A.RealtimeDGT)
+    assert isinstance(s.realtime(), A.RealtimeSTFT) and s.realtime().inversion_mode == "random"
+    with pytest.raises(ValueError):
+        A.STFT(window="nope")
+    with pytest.raises(ValueError):
+        A.STFT(inversion_mode="nope")
+    with pytest.raises(AssertionError):
+        A.STFT(n_fft=1024, hop_length=None)
+    with pytest.raises(AttributeError):
+        s.set_inversion_mode("nope")
+    s.set_inversion_mode("random")
+    s.set_params(512, 128)
+    assert s.ratio == 128 and float(s.window[512:].abs().sum()) == 0
+    with pytest.raises(TypeError):
+        s + 1
+    c = A.STFT() + A.Magnitude()
+    assert isinstance(c, A.ComposeAudioTransform) and len(c) == 2 and c.ratio == 256 and c.needs_scaling and c.invertible
+    c3 = A.OverlapAdd() + c
+    assert len(c3) == 3 and isinstance(c3[0], A.OverlapAdd)
+    assert not (A.STFT() + A.MFCC()).invertible
+    with pytest.raises(A.NotInvertibleError):
+        A.MFCC().invert(torch.zeros(1))
+    with pytest.raises(TypeError):
+        A.Magnitude(contrast="nope").contrast(torch.zeros(1))
+    rc = c.realtime()
+    assert isinstance(rc[0], A.RealtimeSTFT)
+    assert A.OverlapAdd().ratio == 1 and int(A.OverlapAdd().hop_length) == 128     # default hop is 128 (oadd.py:23)
+
+
+def test_no_cpu_fallback():
+    for mod, x in [(A.STFT(), torch.zeros(2, 4096)), (A.DGT(), torch.zeros(2, 4096)),
+                   (A.Magnitude(mode=None), torch.zeros(2, 5, 513, dtype=torch.complex64)),
+                   (A.MFCC(), torch.zeros(2, 4096)), (A.OverlapAdd(1024, 256), torch.zeros(2, 4096)),
+                   (A.MuLaw(), torch.zeros(2, 100)), (A.RealtimeDGT(), torch.zeros(2, 3, 1024))]:
+        with pytest.raises(A.AcidsHipError):
+            mod(x)
+    with pytest.raises(A.AcidsHipError):
+        A.DGT().invert(torch.zeros(2, 5, 513), inversion_mode="pghi")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The .so loads and exports exactly what include/acids_hip.h declares (no compute without a GPU)."""
+    hdr = open(os.path.join(ROOT, "include", "acids_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(at_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    so = os.path.join(ROOT, "acids_transforms_amd", "libacids_hip.so")
+    assert os.path.exists(so), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    L = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(L, name), "missing export: " + name
+    assert sorted(_lib.exported_symbols()) == declared            # the Python binding covers the whole ABI
+    lib = _lib.lib()
+    assert lib.at_abi_version() == 1
+    assert lib.at_error_string(-2).decode() == "unsupported configuration"
+    assert lib.at_istft_workspace_bytes(4, 10, 1024, 256) == 0
+    assert lib.at_istft_workspace_bytes(4, 10, 512, 128) == 4 * 10 * 512 * 4
+    assert lib.at_pghi_offline_workspace_bytes(2, 10, 513) >= 2 * (3 * 5130 * 4 + 5132 * 8)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, "acids_transforms_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in src.lower().replace("# oracle", ""), os.path.join(dirpath, f)
+    import acids_transforms_amd  # noqa: F401
+    import sys
+    assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules
+                   if "acids_transforms_amd" in getattr(sys.modules[m], "__name__", "") and False)
+
+
+def test_melbank_properties():
+    from acids_transforms_amd.utils.melbank import melscale_fbanks
+    fb = melscale_fbanks(513, 0.0, 22050.0, 513, 44100)
+    assert int((fb.sum(0) == 0).sum()) == 109 and int((fb != 0).sum()) == 1019
+    fb128 = melscale_fbanks(513, 0.0, 22050.0, 128, 44100)
+    assert fb128.shape == (513, 128) and float(fb128.min()) >= 0 and float(fb128.max()) <= 1.0
+    peaks = fb128[:, 5:].argmax(0)
+    assert bool((peaks[1:] >= peaks[:-1]).all())          # centre frequencies increase
