@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- spectrogram frames/s (fwd + invert), n_fft=1024 hop=256 (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic audio that is
+already resident in HBM:
+    X    = STFT.forward(x)                       (B, 690, 513) complex64
+    feat = Magnitude(mel, n_mels=128).forward(X) (B, 690, 128) float32, log1p + unipolar normalise
+    y    = STFT.invert(X)                        (B, 176384)   float32
+on BASELINE config[1]: batch = 1024 clips x 4 s @ 44.1 kHz mono per GPU, fp32.
+N > 1: one process per GPU (launched by torch.distributed.run), clips sharded,
+weak scaling, no data-path collective; `value` is the whole-job frames/s.
+Extra figures (all-gather of the features over RCCL, PGHI round trip, per-kernel
+roofline, CPU baseline) ride along in the same JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+N_FFT, HOP, SR = 1024, 256, 44100
+CLIP_LEN = 4 * SR                     # 176400 samples
+T_FRAMES = 1 + CLIP_LEN // HOP        # 690
+F_BINS = N_FFT // 2 + 1               # 513
+N_MELS = 128
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s, ~6.3 achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3          # fp32-input MFMA spec
+# algorithmic bytes per frame
+BYTES_STFT_FWD = HOP * 4 + F_BINS * 8            # 5128
+BYTES_ISTFT = F_BINS * 8 + HOP * 4               # 5128
+BYTES_MEL = F_BINS * 8 + N_MELS * 4              # 4616 (unfused: reads the complex spectrum)
+FLOPS_MEL = 2 * F_BINS * N_MELS                  # 131328 dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the all-gather / PGHI side measurements")
+    ap.add_argument("--pghi-clips", type=int, default=256)
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_clips=96, reps=3):
+    """The oracle (CPU restatement, torch CPU ops) timed on this box's host cores on a bounded
+    sample of the same workload: STFT fwd + Magnitude(mel128) + ISTFT."""
+    from oracle import oracle as O
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(sample_clips, CLIP_LEN, generator=g) * 0.1
+    w = O.hann_window(N_FFT)
+    fwd, _ = O.magnitude_banks(O.melscale_fbanks(F_BINS, 0.0, SR / 2, N_MELS, SR))
+    X = O.stft_forward(x[:4], w, N_FFT, HOP)
+    off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
+
+    def step():
+        X = O.stft_forward(x, w, N_FFT, HOP)
+        O.magnitude_forward(X, fwd, "log1p", off, sc)
+        O.istft(X, w, N_FFT, HOP)
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < reps or (time.perf_counter() - t0 < 10.0 and n < 50):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": sample_clips * T_FRAMES / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d clips x 4 s (%d frames) per pass, %d passes, oracle = torch CPU stft+matmul+istft, %d threads"
+                      % (sample_clips, sample_clips * T_FRAMES, n, threads)}
+
+
+def cpu_baseline_pghi(clips=2, frames=173):
+    """oracle/pghi_ref.c (exact-order C PGHI) on one host core, dense-noise magnitudes."""
+    from oracle import oracle as O
+    import numpy as np
+    rng = np.random.RandomState(7)
+    mag = np.abs(rng.randn(clips, frames, F_BINS) + 1j * rng.randn(clips, frames, F_BINS)).astype(np.float32)
+    t0 = time.perf_counter()
+    O.pghi_offline_batch(mag, N_FFT, HOP)
+    dt = time.perf_counter() - t0
+    return {"value": clips * frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d clips x %d frames dense noise, exact-heap C PGHI, 1 thread" % (clips, frames)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no ROCm device: bench.py measures the HIP path only"}))
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import acids_transforms_amd as A
+    from acids_transforms_amd import ops
+
+    B = args.batch
+    frames_per_step = B * T_FRAMES
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(B, CLIP_LEN, device=dev, generator=gen) * 0.1      # synthetic audio, resident in HBM
+    stft = A.STFT(sr=SR, n_fft=N_FFT, hop_length=HOP).to(dev)
+    mag = A.Magnitude(sr=SR, n_fft=N_FFT, n_mels=N_MELS, mode="unipolar", contrast="log1p").to(dev)
+    X = stft(x[:8])
+    mag.scale_data(X)                                                  # one-off calibration, outside the timed region
+    del X
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    ktimes = {"stft_fwd": [], "mel": [], "istft": []}
+
+    def step(record=False):
+        if record:
+            e = [ev() for _ in range(4)]
+            e[0].record()
+        X = stft(x)
+        if record:
+            e[1].record()
+        feat = mag(X)
+        if record:
+            e[2].record()
+        y = stft.invert(X)
+        if record:
+            e[3].record()
+            return X, feat, y, e
+        return X, feat, y, None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs = []
+    for _ in range(args.steps):
+        out = step(record=True)
+        evs.append(out[3])
+    del out
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    for e in evs:
+        ktimes["stft_fwd"].append(e[0].elapsed_time(e[1]))
+        ktimes["mel"].append(e[1].elapsed_time(e[2]))
+        ktimes["istft"].append(e[2].elapsed_time(e[3]))
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * frames_per_step * args.steps / elapsed
+
+    avg = {k: sum(v) / len(v) for k, v in ktimes.items()}
+
+    def hbm_entry(name, bytes_per_frame):
+        a = frames_per_step * bytes_per_frame / (avg[name] * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(avg[name], 4),
+                "algorithmic_bytes_per_frame": bytes_per_frame}
+
+    kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD), hbm_entry("istft", BYTES_ISTFT), hbm_entry("mel", BYTES_MEL)]
+    mel_tflops = frames_per_step * FLOPS_MEL / (avg["mel"] * 1e-3) / 1e12
+    kernels.append({"kernel": "mel", "bound": "mfma", "achieved": round(mel_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(mel_tflops / MFMA_F32_PEAK_TFLOPS, 4), "ms": round(avg["mel"], 4)})
+    dominant = max(("stft_fwd", "istft"), key=lambda k: avg[k])
+    roof = dict(next(k for k in kernels if k["kernel"] == dominant and k["bound"] == "hbm"))
+    roof.pop("algorithmic_bytes_per_frame")
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dominant)
+        except Exception:
+            traffic = None
+    roof["traffic"] = traffic
+    roof["kernel"] = {"stft_fwd": "stft1024_fwd_kernel", "istft": "istft1024_ola_kernel"}[dominant]
+
+    extras = {}
+    if not args.no_extras:
+        # (a) features reassembled on every rank with one RCCL all-gather, overlapped with the next step's compute
+        if world > 1:
+            from acids_transforms_amd.dist import all_gather_features
+            comm = torch.cuda.Stream(device=dev)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            pending = None
+            for _ in range(args.steps):
+                _, feat, _, _ = step()
+                done = torch.cuda.Event()
+                done.record()
+                if pending is not None:
+                    pending.wait()
+                with torch.cuda.stream(comm):
+                    comm.wait_event(done)
+                    feat.record_stream(comm)
+                    _, pending = all_gather_features(feat, world * B, async_op=True)
+            if pending is not None:
+                pending.wait()
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t1
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            extras["with_feature_allgather_frames_per_s"] = world * frames_per_step * args.steps / float(tt.item())
+        # (b) BASELINE config 3: DGT + PGHI invert round trip, dense noise (worst case: every bin above tolerance)
+        if rank == 0 and args.pghi_clips > 0:
+            dgt = A.DGT(sr=SR, n_fft=N_FFT, hop_length=HOP).to(dev)
+            pb = min(args.pghi_clips, B)
+            m = dgt(x[:pb]).abs()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            yp = dgt.invert(m, inversion_mode="pghi")
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            extras["pghi_invert"] = {"clips": pb, "frames_per_s": pb * T_FRAMES / dt, "seconds": dt,
+                                     "input": "|DGT(randn*0.1)|, ~100% of bins above tolerance",
+                                     "pops_per_s": pb * T_FRAMES * F_BINS / dt}
+            del m, yp
+        barrier()
+
+    result = {
+        "metric": "spectrogram frames/sec (fwd+invert), n_fft=1024 hop=256",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: batch=%d clips/GPU x 4 s mono 44.1 kHz, STFT fwd + Magnitude(mel=128, log1p, "
+                               "unipolar) + ISTFT invert, fp32" % B,
+                   "n_fft": N_FFT, "hop": HOP, "frames_per_clip": T_FRAMES, "clips_per_gpu": B,
+                   "sharding": "clips, no data-path collective"},
+        "roofline": roof,
+        "kernels": kernels,
+    }
+    result.update(extras)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+        result["cpu_baseline_pghi"] = cpu_baseline_pghi()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

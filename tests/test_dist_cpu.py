@@ -1,0 +1,69 @@
+"""world_size-2 gloo test of the clip-sharding + all-gather path (CPU, no kernels:
+the per-clip function is a stand-in; the HIP transforms have no CPU route)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_clips, q):
+    sys.path.insert(0, ROOT)
+    from acids_transforms_amd.dist import shard_batch, shard_bounds, all_gather_features, sharded_apply
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        x = torch.randn(n_clips, 50)                       # replicated batch
+
+        def fn(t):                                          # any per-clip (row-independent) function
+            return torch.stack([t.cumsum(-1), t * t], 1)
+
+        full = fn(x)
+        mine = shard_batch(x)
+        lo, hi = shard_bounds(n_clips, rank, world)
+        assert mine.shape[0] == hi - lo and torch.equal(mine, x[lo:hi])
+        out = sharded_apply(fn, x, gather=True)
+        assert out.shape == full.shape and torch.equal(out, full)
+        local = sharded_apply(fn, x, gather=False)
+        assert torch.equal(local, full[lo:hi])
+        out2, work = all_gather_features(local, n_clips, async_op=True)
+        if work is not None:
+            work.wait()
+        assert torch.equal(out2, full)
+        q.put((rank, "ok"))
+    except Exception as e:                                  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [8, 7])
+def test_shard_and_all_gather_gloo(n_clips):
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + n_clips
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_shard_bounds_cover_everything():
+    from acids_transforms_amd.dist import shard_bounds
+    for n in [0, 1, 7, 8, 1024, 8191]:
+        for w in [1, 2, 3, 8]:
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
