@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libacids_hip.so")
+_SO = os.environ.get("ACIDS_HIP_LIB") or os.path.join(_HERE, "libacids_hip.so")   # override: kernel A/B experiments
 
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_i64 = ctypes.c_int64

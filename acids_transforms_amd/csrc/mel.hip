@@ -13,8 +13,8 @@
 //   * wave w owns 16 output columns of a 128-column block; its slice of the
 //     bank (K x 16, <= 128 VGPRs) stays in registers for the whole launch;
 //   * the workgroup walks 32-row tiles of the input; |.| is taken once while
-//     the tile is staged in LDS (row stride 64q+4 floats: conflict-free
-//     ds_read_b64 A-fragments), double buffered, the next tile's global loads
+//     the tile is staged in LDS (row stride 32q+2 floats: conflict-free
+//     ds_read2_b64 A-fragments), double buffered, the next tile's global loads
 //     interleaved with the current tile's MFMAs; one barrier per tile;
 //   * epilogue straight from the accumulators (contrast, (x-offset)/scale).
 #include <hip/hip_runtime.h>
@@ -65,9 +65,16 @@ __device__ __forceinline__ float contrast_inv(float v, int mode, float eps) {
   }
 }
 
-__device__ __forceinline__ float load_a(const MelParams& p, long long row, int k, float off, float sc) {
+// raw element of A as loaded from HBM (complex pair, or a real value in .x)
+__device__ __forceinline__ float2 load_raw(const MelParams& p, long long row, int k) {
+  if (p.a_kind >= A_REAL) return make_float2(reinterpret_cast<const float*>(p.A)[row * p.lda + k], 0.f);
+  return reinterpret_cast<const float2*>(p.A)[row * p.lda + k];
+}
+
+// what the contraction consumes: |.|, |.|^2, or the (de-normalised, de-contrasted) real value
+__device__ __forceinline__ float finish_a(const MelParams& p, float2 c, float off, float sc) {
   if (p.a_kind >= A_REAL) {
-    float v = reinterpret_cast<const float*>(p.A)[row * p.lda + k];
+    float v = c.x;
     if (p.a_kind == A_REAL_ABS) v = fabsf(v);
     if (p.inverse) {
       if (p.offset) v = __fadd_rn(__fmul_rn(v, sc), off);
@@ -75,34 +82,47 @@ __device__ __forceinline__ float load_a(const MelParams& p, long long row, int k
     }
     return v;
   }
-  float2 c = reinterpret_cast<const float2*>(p.A)[row * p.lda + k];
-  if (p.a_kind == A_COMPLEX_ABS2) return c.x * c.x + c.y * c.y;
-  return hypotf(c.x, c.y);
+  const float s2 = fmaf(c.x, c.x, c.y * c.y);
+  return (p.a_kind == A_COMPLEX_ABS2) ? s2 : __builtin_amdgcn_sqrtf(s2);  // |x| (overflow-safe hypot is not needed at audio scale)
 }
 
-// stage rows [r0, r0+4) x all K of tile `tile` (piece c = r0/4) : issue loads
+__device__ __forceinline__ float load_a(const MelParams& p, long long row, int k, float off, float sc) {
+  return finish_a(p, load_raw(p, row, k), off, sc);
+}
+
+// stage rows [4c, 4c+4) x all K of tile `tile` (piece c): issue the global loads only
 template <int NL>
-__device__ __forceinline__ void piece_load(const MelParams& p, long long tile, int piece, float (&regs)[NL], float off,
-                                           float sc) {
+__device__ __forceinline__ void piece_load(const MelParams& p, long long tile, int piece, float2 (&regs)[NL]) {
   const int tr = piece * 4 + (threadIdx.x >> 7);
   const long long row = tile * ROWS + tr;
   const int kseg = threadIdx.x & 127;
+  const bool row_ok = row < p.rows;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int k = kseg + 128 * i;
-    regs[i] = (row < p.rows && k < p.K) ? load_a(p, row, k, off, sc) : 0.0f;
+    // all but the last 128-column segment are always inside K (NL = ceil(K/128))
+    const bool ok = row_ok && (i + 1 < NL || k < p.K);
+    regs[i] = ok ? load_raw(p, row, k) : make_float2(0.f, 0.f);
   }
 }
 
+// ... and, one MFMA group later, take |.| and park the piece in LDS
 template <int NL>
-__device__ __forceinline__ void piece_store(const MelParams& p, int piece, const float (&regs)[NL], float* buf) {
+__device__ __forceinline__ void piece_store(const MelParams& p, int piece, const float2 (&regs)[NL], float* buf,
+                                            float off, float sc, int* nonfinite_flag) {
   const int tr = piece * 4 + (threadIdx.x >> 7);
   const int kseg = threadIdx.x & 127;
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int k = kseg + 128 * i;
-    if (k < p.K) buf[tr * p.rs + k] = regs[i];
+    if (i + 1 < NL || k < p.K) {
+      const float v = finish_a(p, regs[i], off, sc);
+      bad |= !(fabsf(v) <= 3.402823466e+38f);   // inf or NaN
+      buf[tr * p.rs + k] = v;
+    }
   }
+  if (bad) *nonfinite_flag = 1;  // this tile must take the dense path (0 * NaN has to stay NaN)
 }
 
 // KSTEPS = number of 4-deep MFMA steps (K_main = 4*KSTEPS <= K); NL = ceil(K/128) loads per thread per piece
@@ -111,6 +131,9 @@ __global__ __launch_bounds__(THREADS) void mel_gemm_kernel(MelParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* buf0 = smem;
   float* buf1 = smem + ROWS * p.rs;
+  int* flags = reinterpret_cast<int*>(smem + 2 * ROWS * p.rs);   // 3 rotating "tile holds inf/NaN" flags
+  if (threadIdx.x < 3) flags[threadIdx.x] = 0;
+  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -139,12 +162,31 @@ __global__ __launch_bounds__(THREADS) void mel_gemm_kernel(MelParams p) {
   if (tile_end > ntiles) tile_end = ntiles;
   if (tile >= tile_end) return;
 
+  // Zero-block skipping: a j-step (8 bank rows x this wave's 16 columns) whose bank entries are all
+  // exactly zero contributes exactly 0 for finite inputs and is skipped (wave-uniform branch).  Mel
+  // banks are banded, so most steps drop out; a dense bank skips nothing.  Tiles that contain an
+  // inf/NaN take the dense path so that non-finite values propagate as in a dense matmul.
+  unsigned long long nzmask = 0ull;
+#pragma unroll
+  for (int j = 0; j < KSTEPS / 2; ++j)
+    if (__ballot(breg[2 * j] != 0.0f || breg[2 * j + 1] != 0.0f) != 0ull) nzmask |= 1ull << j;
+  nzmask = __builtin_amdgcn_readfirstlane((unsigned)nzmask) |
+           ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(nzmask >> 32)) << 32);
+
+  // K tail (k >= 4*KSTEPS, at most 4 columns kept in registers; longer tails re-read the bank)
+  float btail[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = kmain + q;
+    btail[q] = (col_ok && k < p.K) ? p.Bm[(long long)k * p.ldb + col] : 0.0f;
+  }
+
   // prologue: stage the first tile
   {
-    float regs[NL];
+    float2 regs[NL];
     for (int c = 0; c < 8; ++c) {
-      piece_load<NL>(p, tile, c, regs, off, sc);
-      piece_store<NL>(p, c, regs, buf0);
+      piece_load<NL>(p, tile, c, regs);
+      piece_store<NL>(p, c, regs, buf0, off, sc, &flags[0]);
     }
   }
   __syncthreads();
@@ -152,19 +194,31 @@ __global__ __launch_bounds__(THREADS) void mel_gemm_kernel(MelParams p) {
   float* cur = buf0;
   float* nxt = buf1;
   for (; tile < tile_end; ++tile) {
+#ifdef AT_MEL_ABLATE
+    const bool has_next = false;
+#else
     const bool has_next = tile + 1 < tile_end;
+#endif
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const long long it = tile - (long long)blockIdx.x * p.tiles_per_block;
+    int* flag_cur = flags + (int)(it % 3);
+    int* flag_nxt = flags + (int)((it + 1) % 3);
+    if (threadIdx.x == 0) flags[(int)((it + 2) % 3)] = 0;   // next written one barrier from now
+    const unsigned long long jmask = (__builtin_amdgcn_readfirstlane(*flag_cur) != 0) ? ~0ull : nzmask;
     const float* a0p = cur + li * p.rs + 2 * kk;
     const float* a1p = cur + (16 + li) * p.rs + 2 * kk;
     constexpr int CH = (KSTEPS / 2 + 7) / 8;  // j-iterations per staged piece
+    // two pieces of the next tile in flight: piece c+1 is requested before the MFMAs of group c,
+    // piece c is converted and parked after them
+    float2 regs[2][NL];
+    if (has_next) piece_load<NL>(p, tile + 1, 0, regs[0]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      float regs[NL];
-      if (has_next) piece_load<NL>(p, tile + 1, c, regs, off, sc);
+      if (has_next && c + 1 < 8) piece_load<NL>(p, tile + 1, c + 1, regs[(c + 1) & 1]);
 #pragma unroll
       for (int jj = 0; jj < CH; ++jj) {
         const int j = c * CH + jj;
-        if (j < KSTEPS / 2) {
+        if (j < KSTEPS / 2 && ((jmask >> j) & 1ull)) {
           const float2 a0 = *reinterpret_cast<const float2*>(a0p + 8 * j);
           const float2 a1 = *reinterpret_cast<const float2*>(a1p + 8 * j);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[2 * j], acc0, 0, 0, 0);
@@ -173,11 +227,12 @@ __global__ __launch_bounds__(THREADS) void mel_gemm_kernel(MelParams p) {
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[2 * j + 1], acc1, 0, 0, 0);
         }
       }
-      if (has_next) piece_store<NL>(p, c, regs, nxt);
+      if (has_next) piece_store<NL>(p, c, regs[c & 1], nxt, off, sc, flag_nxt);
     }
     // K tail (k >= 4*KSTEPS) on the vector ALU; C/D layout: col = lane&15, row = 4*(lane>>4) + reg
     for (int k = kmain; k < p.K; ++k) {
-      const float b = col_ok ? p.Bm[(long long)k * p.ldb + col] : 0.0f;
+      const int q = k - kmain;
+      const float b = (q < 4) ? btail[q & 3] : (col_ok ? p.Bm[(long long)k * p.ldb + col] : 0.0f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         acc0[r] = fmaf(cur[(4 * kk + r) * p.rs + k], b, acc0[r]);
@@ -294,7 +349,7 @@ static int launch_mel(const MelParams& p0, hipStream_t stream) {
   if (rowblocks > ntiles) rowblocks = ntiles;
   p.tiles_per_block = (ntiles + rowblocks - 1) / rowblocks;
   rowblocks = (ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
-  const size_t lds = sizeof(float) * 2 * ROWS * (size_t)p.rs;
+  const size_t lds = sizeof(float) * 2 * ROWS * (size_t)p.rs + 16;
   auto kern = mel_gemm_kernel<KSTEPS, NL>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -323,8 +378,9 @@ int at_mel_project(const void* A, int a_kind, int64_t rows, int64_t lda, int K, 
   p.A = A; p.Bm = bank; p.out = out; p.offset = offset; p.scale = scale;
   p.rows = rows; p.lda = lda; p.ld_out = ld_out; p.T = T_transposed;
   p.K = K; p.N = N; p.ldb = ldb; p.a_kind = a_kind; p.contrast = contrast; p.inverse = inverse; p.eps = eps;
-  p.rs = ((K - 4 + 63) / 64) * 64 + 4;
-  if (p.rs < K) p.rs += 64;
+  // LDS row stride (floats).  hipcc fuses the A-fragment reads of a j-pair into ds_read2_b64, which is
+  // serviced in 16-lane groups over 32 banks: consecutive rows must step by 8 B (mod 128 B) => rs = 32q + 2
+  p.rs = ((K - 2 + 31) / 32) * 32 + 2;
   p.tiles_per_block = 1;
   hipStream_t s = (hipStream_t)stream;
   if (K > 576 || K < 16) {

@@ -168,3 +168,27 @@ def test_mfcc_melspectrogram(dev):
     cr = O.mfcc_dct(db, 40).transpose(-1, -2)
     assert c.shape == cr.shape == (3, 2, 40, 24)
     assert rel_max(cpu(c), cr.numpy()) < 2e-5
+
+
+def test_zero_block_skipping_keeps_dense_semantics(dev):
+    """Banded banks skip all-zero bank blocks; results must equal the dense contraction, including
+    inf/NaN propagation (0 * NaN = NaN in a dense matmul), and a dense bank must be unaffected."""
+    from acids_transforms_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows, K, N = 200, 513, 128
+    X = (torch.randn(rows, K, generator=g) * torch.exp(2j * np.pi * torch.rand(rows, K, generator=g))).to(torch.complex64)
+    band = O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100)
+    dense = torch.rand(K, N, generator=g) + 0.1
+    for bank in (band, dense):
+        y = ops.mel_forward(X.to(dev), bank.to(dev), None)
+        yr = torch.matmul(X.abs().double(), bank.double()).float()
+        assert rel_max(cpu(y), yr.numpy()) < TOL
+    Xn = X.clone()
+    Xn[37, 400] = complex(float("nan"), 0.0)        # one poisoned bin in tile 1 (rows 32..63)
+    Xn[150, 3] = complex(float("inf"), 1.0)         # and an inf in tile 4
+    y = cpu(ops.mel_forward(Xn.to(dev), band.to(dev), None))
+    yr = torch.matmul(Xn.abs(), band).numpy()
+    assert np.array_equal(np.isnan(y), np.isnan(yr))
+    assert np.array_equal(np.isinf(y), np.isinf(yr))
+    ok = np.isfinite(yr)
+    assert np.abs(y[ok] - yr[ok]).max() / np.abs(yr[ok]).max() < TOL

@@ -1,0 +1,60 @@
+"""Dev timing of the individual kernels at BASELINE config-2 size (not the bench contract)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import acids_transforms_amd as A
+
+which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["fwd", "inv", "mel128", "mel513"]
+B, L = 1024, 176400
+dev = torch.device("cuda:0")
+x = torch.randn(B, L, device=dev) * 0.1
+m = A.STFT().to(dev)
+T = 1 + L // 256
+frames = B * T
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def report(name, t, bpf, flops=0):
+    extra = "  %6.1f TFLOP/s" % (frames * flops / t / 1e9) if flops else ""
+    print("%-16s %8.3f ms  %8.1f Mframes/s  %6.2f TB/s algorithmic (%.0f%% of 8 TB/s)%s" % (
+        name, t, frames / t / 1e3, frames * bpf / t / 1e9, frames * bpf / t / 1e9 / 8 * 100, extra), flush=True)
+
+
+X = m(x)
+if "fwd" in which:
+    report("stft_fwd", timeit(lambda: m(x)), 5128)
+if "inv" in which:
+    report("istft", timeit(lambda: m.invert(X)), 5128)
+if "mel128" in which:
+    mg = A.Magnitude(n_mels=128, mode=None).to(dev)
+    report("mel128", timeit(lambda: mg(X)), 4104 + 512, 2 * 513 * 128)
+if "mel513" in which:
+    mg = A.Magnitude(mode=None).to(dev)
+    report("mel513", timeit(lambda: mg(X), n=5), 4104 + 2052, 2 * 513 * 513)
+if "polar" in which:
+    mag, ph = X.abs(), X.angle()
+    report("istft_polar", timeit(lambda: m._istft(mag=mag, phase=ph)), 5128)
+if "pghi" in which:
+    d = A.DGT().to(dev)
+    nb = int(os.environ.get("PGHI_B", "256"))
+    mg = d(x[:nb]).abs()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    d.pghi(mg)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("pghi B=%d  %.3f s  %.1f kframes/s  %.2f Mpops/s" % (nb, dt, nb * T / dt / 1e3, nb * T * 513 / dt / 1e6))
