@@ -84,10 +84,27 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// twiddles held in registers (loop invariant, 44 VGPRs) ...
 struct Twiddles {
   float2 t1[7];
   float2 t2[7];
   float2 tr[8];
+  __device__ __forceinline__ float2 get1(int k) const { return t1[k]; }
+  __device__ __forceinline__ float2 get2(int k) const { return t2[k]; }
+  __device__ __forceinline__ float2 getr(int m) const { return tr[m]; }
+};
+
+// ... or read at the point of use from a workgroup-shared LDS copy of the table
+// (tab[row * 64 + lane]: consecutive lanes, conflict-free ds_read_b64), trading 22 LDS reads per
+// frame for 44 VGPRs -- one more resident wave per SIMD in the streaming kernels.
+template <bool INV>
+struct LdsTwiddles {
+  const float2* tab;  // kTwiddleCount float2 in LDS, forward-sign values
+  int lane;
+  __device__ __forceinline__ float2 fix(float2 a) const { return INV ? make_float2(a.x, -a.y) : a; }
+  __device__ __forceinline__ float2 get1(int k) const { return fix(tab[k * 64 + lane]); }
+  __device__ __forceinline__ float2 get2(int k) const { return fix(tab[(7 + k) * 64 + lane]); }
+  __device__ __forceinline__ float2 getr(int m) const { return fix(tab[(14 + m) * 64 + lane]); }
 };
 
 template <bool INV>
@@ -109,12 +126,12 @@ __device__ __forceinline__ void load_twiddles(Twiddles& tw, const float2* __rest
 // 512-point complex FFT of one wave.  In: v[m] = z[lane + 64 m].
 // Out: v[m] = Z[lane + 64 m] (unnormalised).  `lds` is this wave's private slab
 // of kFftLdsFloat2PerWave float2.
-template <bool INV>
-__device__ __forceinline__ void fft512(float2 (&v)[8], const Twiddles& tw, float2* lds, int lane) {
+template <bool INV, typename TW>
+__device__ __forceinline__ void fft512(float2 (&v)[8], const TW& tw, float2* lds, int lane) {
   const int lo = lane & 7, hi = lane >> 3;
   radix8<INV>(v);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.t1[k - 1]);
+  for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.get1(k - 1));
   // xchg 1: writer (n0=lo, n1=hi), element k0 -> index n1*72 + n0 + 8*k0
 #pragma unroll
   for (int k = 0; k < 8; ++k) lds[hi * 72 + lo + 8 * k] = v[k];
@@ -124,7 +141,7 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], const Twiddles& tw, float
   wave_lds_sync();
   radix8<INV>(v);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.t2[k - 1]);
+  for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.get2(k - 1));
   // xchg 2: writer (n0=lo, k0=hi), element k1 -> index n0*66 + k0 + 8*k1
 #pragma unroll
   for (int k = 0; k < 8; ++k) lds[lo * 66 + hi + 8 * k] = v[k];
@@ -157,7 +174,8 @@ __device__ __forceinline__ void mirror512(const float2 (&v)[8], float2 (&p)[8], 
 // real-FFT merge after the forward complex FFT:
 //   X[k] = (Z[k] + conj Z[512-k])/2 - (i/2) W1024^k (Z[k] - conj Z[512-k]),  k = lane + 64 m
 // returns X[512] (Nyquist) in `nyq` (meaningful on lane 0 only).
-__device__ __forceinline__ void rfft_merge(float2 (&v)[8], const Twiddles& tw, int lane, float2& nyq) {
+template <typename TW>
+__device__ __forceinline__ void rfft_merge(float2 (&v)[8], const TW& tw, int lane, float2& nyq) {
   float2 p[8];
   mirror512(v, p, lane);
   nyq = make_float2(v[0].x - v[0].y, 0.0f);
@@ -166,7 +184,7 @@ __device__ __forceinline__ void rfft_merge(float2 (&v)[8], const Twiddles& tw, i
     float2 zp = cconj(p[m]);
     float2 e = make_float2(0.5f * (v[m].x + zp.x), 0.5f * (v[m].y + zp.y));
     float2 d = make_float2(0.5f * (v[m].x - zp.x), 0.5f * (v[m].y - zp.y));
-    float2 wd = cmul(tw.tr[m], d);  // W^k * d
+    float2 wd = cmul(tw.getr(m), d);  // W^k * d
     // -i * wd = (wd.y, -wd.x)
     v[m] = make_float2(e.x + wd.y, e.y - wd.x);
   }
@@ -176,7 +194,8 @@ __device__ __forceinline__ void rfft_merge(float2 (&v)[8], const Twiddles& tw, i
 // build Z[k] = E[k] + i O[k] with E = (X[k] + conj X[512-k]), O = (X[k] - conj X[512-k]) conj(W1024^k)
 // (the common factor 1/2 is folded into the caller's 1/N scale).
 // `tw` must have been loaded with INV = true (tr = conj W1024^k).
-__device__ __forceinline__ void irfft_split(float2 (&v)[8], const Twiddles& tw, int lane, float xnyq_re) {
+template <typename TW>
+__device__ __forceinline__ void irfft_split(float2 (&v)[8], const TW& tw, int lane, float xnyq_re) {
   // c2r ignores the imaginary parts of DC and Nyquist
   if (lane == 0) v[0].y = 0.0f;
   float2 p[8];
@@ -186,7 +205,7 @@ __device__ __forceinline__ void irfft_split(float2 (&v)[8], const Twiddles& tw, 
   for (int m = 0; m < 8; ++m) {
     float2 xp = cconj(p[m]);
     float2 e = cadd(v[m], xp);
-    float2 d = cmul(csub(v[m], xp), tw.tr[m]);
+    float2 d = cmul(csub(v[m], xp), tw.getr(m));
     // Z = e + i d
     v[m] = make_float2(e.x - d.y, e.y + d.x);
   }

@@ -133,6 +133,153 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stft1024_fwd_kernel(FwdP
 }
 
 // ---------------------------------------------------------------------------
+// forward, hop = 256 = N/4, center=True: sliding-window variant.
+// A wave walks a run of consecutive frames of one clip.  Frame t+1 shares 768 of
+// its 1024 samples with frame t, and in the lane layout z[l + 64 m] that overlap
+// is exactly "registers m+2 of the same lane": the raw samples stay in registers,
+// shifted by two slots per frame, and only the 256 new samples (two 8-byte loads
+// per lane) are fetched per frame -- 1 KB of loads per frame instead of 4 KB.
+// ---------------------------------------------------------------------------
+struct FwdRunParams {
+  const float* x;
+  const float* window;
+  const float2* tw;
+  float2* out;
+  float* phase;
+  long long B, L, clip_stride, T;
+  long long runs_per_clip, frames_per_run;
+};
+
+// element n = lane + 64 m of the frame starting at padded position p0 (original index p0 - 512 + 2n)
+__device__ __forceinline__ float2 load_pair(const float* clip, long long L, long long i0, bool interior, bool aligned,
+                                            int lane_off) {
+  // i0: original index of the first sample of this 64-lane, 128-sample segment; lane_off = 2*lane
+  if (interior) {
+    if (aligned) return reinterpret_cast<const float2*>(clip + i0)[lane_off >> 1];
+    return make_float2(clip[i0 + lane_off], clip[i0 + lane_off + 1]);
+  }
+  return make_float2(clip[reflect_index(i0 + lane_off, L)], clip[reflect_index(i0 + lane_off + 1, L)]);
+}
+
+constexpr int FWD_WAVES = 4;  // 5 x 4.5 KB slabs + 15 KB tables = 37.7 KB -> 4 blocks = 20 waves per CU
+
+template <bool WRITE_PHASE>
+__global__ __launch_bounds__(64 * FWD_WAVES) void stft1024_h256_fwd_kernel(FwdRunParams p) {
+  __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTwiddleCount + 512];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* tab = lds_all + FWD_WAVES * kFftLdsFloat2PerWave;
+  // workgroup-shared constants: twiddle table and analysis window
+  for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * FWD_WAVES) tab[i] = p.tw[i];
+  for (int i = threadIdx.x; i < 512; i += 64 * FWD_WAVES)
+    tab[kTwiddleCount + i] = reinterpret_cast<const float2*>(p.window)[i];
+  __syncthreads();
+
+  const long long run = (long long)blockIdx.x * FWD_WAVES + wave;
+  const long long b = run / p.runs_per_clip;
+  if (b >= p.B) return;
+  const long long r = run - b * p.runs_per_clip;
+  const long long t0 = r * p.frames_per_run;
+  long long t1 = t0 + p.frames_per_run;
+  if (t1 > p.T) t1 = p.T;
+  if (t0 >= t1) return;
+
+  Twiddles tw;
+  load_twiddles<false>(tw, p.tw, lane);
+  const float2* win = tab + kTwiddleCount;   // win[lane + 64 m]
+
+  const float* clip = p.x + b * p.clip_stride;
+  const bool clip_aligned = ((((uintptr_t)clip) & 7) == 0);  // frame starts are multiples of 256 samples
+  const long long L = p.L;
+  const int lane2 = 2 * lane;
+
+  // first frame of the run: all eight segments
+  float2 raw[8];
+  {
+    const long long s0 = t0 * 256 - 512;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const long long i0 = s0 + 128 * m;
+      raw[m] = load_pair(clip, L, i0, i0 >= 0 && i0 + 128 <= L, clip_aligned, lane2);
+    }
+  }
+  // Make the prologue loads architecturally complete here: otherwise the loop-top wait is the merge of
+  // "just loaded" (from this prologue) and "loaded nine stores ago" (from the back edge) and collapses to
+  // vmcnt(0), which would drain every frame's stores before the next frame starts.
+#pragma unroll
+  for (int m = 0; m < 8; ++m) asm volatile("" : "+v"(raw[m].x), "+v"(raw[m].y));
+  float2* row = p.out + (b * p.T + t0) * F;
+  float* prow = WRITE_PHASE ? p.phase + (b * p.T + t0) * F : nullptr;
+
+  // one frame: window, FFT, merge, store; `n6`/`n7` are the next frame's two new segments, already requested.
+  // The Nyquist bin (a one-lane, exec-masked store the compiler cannot count on) is deferred to the top of the
+  // next iteration, *before* that iteration's loads: the wait for the prefetched samples then has exactly
+  // eight younger stores behind it and leaves all of them in flight.
+  float2 nyq_pending = make_float2(0.f, 0.f);
+  float2* nyq_dst = nullptr;
+  auto flush_nyquist = [&]() {
+    if (nyq_dst != nullptr && lane == 0) *nyq_dst = nyq_pending;
+    if (WRITE_PHASE && nyq_dst != nullptr && lane == 0)
+      p.phase[(nyq_dst - p.out)] = atan2f(nyq_pending.y, nyq_pending.x);
+  };
+  auto frame_body = [&](float2 n6, float2 n7) {
+    float2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float2 w = win[lane + 64 * m];
+      v[m] = make_float2(raw[m].x * w.x, raw[m].y * w.y);
+    }
+#pragma unroll
+    for (int m = 0; m < 6; ++m) raw[m] = raw[m + 2];
+    raw[6] = n6;
+    raw[7] = n7;
+    fft512<false>(v, tw, lds, lane);
+    float2 nyq;
+    rfft_merge(v, tw, lane, nyq);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) row[lane + 64 * m] = v[m];
+    if (WRITE_PHASE) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) prow[lane + 64 * m] = atan2f(v[m].y, v[m].x);
+      prow += F;
+    }
+    nyq_pending = nyq;
+    nyq_dst = row + 512;
+    row += F;
+  };
+
+  // Frames whose successor's new samples [256 t + 512, 256 t + 768) lie inside the clip take the
+  // branch-free loop: two unconditional 8-byte loads issued *before* this frame's stores, so the
+  // compiler's vmcnt accounting lets the stores stay in flight across iterations.
+  long long t = t0;
+  long long t_fast_end = (L - 768) / 256 + 1;          // first t for which the successor needs reflection
+  if (t_fast_end > t1 - 1) t_fast_end = t1 - 1;        // the last frame of the run has no successor to fetch
+  if (!clip_aligned) t_fast_end = t0;                  // odd-length clips: generic loop only
+  if (t < t_fast_end) {
+    const float2* nsrc = reinterpret_cast<const float2*>(clip + (t + 1) * 256 + 256) + lane;  // segment 6 of frame t+1
+    for (; t < t_fast_end; ++t) {
+      flush_nyquist();
+      const float2 n6 = nsrc[0];
+      const float2 n7 = nsrc[64];
+      nsrc += 128;
+      frame_body(n6, n7);
+    }
+  }
+  for (; t < t1; ++t) {
+    flush_nyquist();
+    float2 n6 = make_float2(0.f, 0.f), n7 = n6;
+    if (t + 1 < t1) {
+      const long long i6 = (t + 1) * 256 - 512 + 768;
+      n6 = load_pair(clip, L, i6, i6 >= 0 && i6 + 128 <= L, clip_aligned, lane2);
+      n7 = load_pair(clip, L, i6 + 128, i6 + 128 >= 0 && i6 + 256 <= L, clip_aligned, lane2);
+    }
+    frame_body(n6, n7);
+  }
+  flush_nyquist();
+}
+
+// ---------------------------------------------------------------------------
 // inverse
 // ---------------------------------------------------------------------------
 enum { IN_COMPLEX = 0, IN_POLAR = 1 };
@@ -152,6 +299,16 @@ struct InvParams {
   long long total_frames, frames_per_block;  // OUT_FRAMES
 };
 
+// cos/sin of an unwrapped phase that may be ~1e5 rad (PGHI): reduce in fp64 to revolutions in
+// [-0.5, 0.5] (exact to ~1e-16), then the hardware sin/cos (v_sin_f32 takes revolutions; abs error ~1e-6).
+__device__ __forceinline__ void sincos_big(float phase, float& s, float& c) {
+  double t = (double)phase * 0.15915494309189533577;  // 1 / (2 pi)
+  t -= rint(t);
+  const float r = (float)t;
+  s = __builtin_amdgcn_sinf(r);
+  c = __builtin_amdgcn_cosf(r);
+}
+
 template <int IN_MODE>
 __device__ __forceinline__ void load_spectrum(const InvParams& p, long long f, int lane, float2 (&v)[8], float& nyq_re) {
   if (IN_MODE == IN_COMPLEX) {
@@ -166,23 +323,27 @@ __device__ __forceinline__ void load_spectrum(const InvParams& p, long long f, i
     for (int m = 0; m < 8; ++m) {
       float a = mrow[lane + 64 * m];
       float s, c;
-      sincosf(prow[lane + 64 * m], &s, &c);
+      sincos_big(prow[lane + 64 * m], s, c);
       v[m] = make_float2(a * c, a * s);
     }
     float s, c;
-    sincosf(prow[512], &s, &c);
+    sincos_big(prow[512], s, c);
     nyq_re = mrow[512] * c;
   }
 }
 
 // one frame: spectrum -> windowed time samples y[m] = (x[2n], x[2n+1]) * w, n = lane + 64 m
-__device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const Twiddles& tw, const float2 (&win)[8],
+template <typename TW>
+__device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const TW& tw, const float2* win,
                                             float2* lds, int lane) {
   irfft_split(v, tw, lane, nyq_re);
   fft512<true>(v, tw, lds, lane);
   const float s = 1.0f / 1024.0f;
 #pragma unroll
-  for (int m = 0; m < 8; ++m) v[m] = make_float2((v[m].x * s) * win[m].x, (v[m].y * s) * win[m].y);
+  for (int m = 0; m < 8; ++m) {
+    const float2 w = win[lane + 64 * m];   // synthesis window, workgroup-shared LDS copy
+    v[m] = make_float2((v[m].x * s) * w.x, (v[m].y * s) * w.y);
+  }
 }
 
 // K3: irFFT + window + overlap-add (hop = 256 = N/4) + envelope division + centre trim.
@@ -190,10 +351,13 @@ __device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const 
 // j0-1 .. j1+1 with the four overlapping frames' partial sums in registers.
 template <int IN_MODE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void istft1024_ola_kernel(InvParams p) {
-  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave];
+  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave + 512];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* win = lds_all + WAVES_PER_BLOCK * kFftLdsFloat2PerWave;
+  for (int i = threadIdx.x; i < 512; i += 64 * WAVES_PER_BLOCK) win[i] = reinterpret_cast<const float2*>(p.window)[i];
+  __syncthreads();
 
   const long long run = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
   const long long b = run / p.runs_per_clip;
@@ -207,9 +371,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void istft1024_ola_kernel(Inv
 
   Twiddles tw;
   load_twiddles<true>(tw, p.tw, lane);
-  float2 win[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) win[m] = reinterpret_cast<const float2*>(p.window)[lane + 64 * m];
 
   float2 acc[8];
 #pragma unroll
@@ -261,15 +422,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void istft1024_ola_kernel(Inv
 // K5: irFFT + window, frames out (no overlap-add): RealtimeSTFT/RealtimeDGT.invert
 template <int IN_MODE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void irfft1024_frames_kernel(InvParams p) {
-  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave];
+  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave + 512];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* win = lds_all + WAVES_PER_BLOCK * kFftLdsFloat2PerWave;
+  for (int i = threadIdx.x; i < 512; i += 64 * WAVES_PER_BLOCK) win[i] = reinterpret_cast<const float2*>(p.window)[i];
+  __syncthreads();
   Twiddles tw;
   load_twiddles<true>(tw, p.tw, lane);
-  float2 win[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) win[m] = reinterpret_cast<const float2*>(p.window)[lane + 64 * m];
   const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
   long long f_end = f_begin + p.frames_per_block;
   if (f_end > p.total_frames) f_end = p.total_frames;
@@ -322,6 +483,31 @@ int launch_stft1024_fwd(const float* x, long long B, long long L, long long clip
     hipLaunchKernelGGL(stft1024_fwd_kernel<true>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
   else
     hipLaunchKernelGGL(stft1024_fwd_kernel<false>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long clip_stride, long long T,
+                             const float* window, const float2* tw, float2* out, float* phase, hipStream_t stream) {
+  FwdRunParams p;
+  p.x = x; p.window = window; p.tw = tw; p.out = out; p.phase = phase;
+  p.B = B; p.L = L; p.clip_stride = clip_stride; p.T = T;
+  if (B * T == 0) return 0;
+  // ~16 waves per CU; runs of at least 24 frames so that the 3 extra segment loads of a run start stay < 5 %
+  long long target_waves = (long long)num_cus() * 20;
+  long long runs_per_clip = (target_waves + B - 1) / B;
+  if (runs_per_clip < 1) runs_per_clip = 1;
+  long long fpr = (T + runs_per_clip - 1) / runs_per_clip;
+  if (fpr < 24) fpr = 24;
+  if (fpr > T) fpr = T;
+  runs_per_clip = (T + fpr - 1) / fpr;
+  p.runs_per_clip = runs_per_clip;
+  p.frames_per_run = fpr;
+  long long waves = B * runs_per_clip;
+  long long blocks = (waves + FWD_WAVES - 1) / FWD_WAVES;
+  if (phase)
+    hipLaunchKernelGGL(stft1024_h256_fwd_kernel<true>, dim3((unsigned)blocks), dim3(64 * FWD_WAVES), 0, stream, p);
+  else
+    hipLaunchKernelGGL(stft1024_h256_fwd_kernel<false>, dim3((unsigned)blocks), dim3(64 * FWD_WAVES), 0, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
