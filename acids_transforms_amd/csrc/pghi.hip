@@ -16,6 +16,7 @@
 // the reference's rounding sequence (no FMA contraction).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/acids_hip.h"
 
@@ -247,6 +248,213 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_kernel(HgiParams p) {
     if (lane == 0) {
       heap[0].key = -max_val;
       heap[0].idx = (int)max_pos;
+      spec[max_pos] = abstol;
+    }
+    hn = 1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  if (p.npops && lane == 0) p.npops[b] = npops;
+}
+
+// ---------------------------------------------------------------------------
+// K14 offline, wave-cooperative heap.  Same binary heap, same sift rules, same
+// pop order as the single-lane version above -- but every heap operation is done
+// by the whole wavefront so that its ~log2(n) *dependent* memory accesses become
+// a few wide ones:
+//   pop  : the bubble-up path from the hole is resolved five levels per round:
+//          63 lanes gather the depth-6 subtree under the hole (node i of the
+//          subtree on lane i), every inner lane picks its smaller child (right
+//          child on ties, utils/heapq.py:33), the path is read off with five
+//          v_readlane steps and all moved entries are written by one store;
+//   push / final sift-down: every ancestor of the insertion point is known from
+//          its index alone, so lane L loads ancestor L, one ballot finds how far
+//          the item rises (strict '<', heapq.py:16) and one store shifts the chain;
+//   neighbours: lanes 0-3 handle next-frame / prev-frame / next-bin / prev-bin.
+// Heap words are read with agent-scope loads (L2-served): entries written by one
+// lane are re-read by other lanes of the same wave a few instructions later.
+// ---------------------------------------------------------------------------
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 pack_item(float key, int idx) {
+  return ((u64)__float_as_uint(key) << 32) | (unsigned)idx;
+}
+__device__ __forceinline__ float item_key(u64 e) { return __uint_as_float((unsigned)(e >> 32)); }
+__device__ __forceinline__ int item_idx(u64 e) { return (int)(unsigned)e; }
+
+__device__ __forceinline__ u64 hload(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hstore(u64* p, u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+  const unsigned lo = __shfl((unsigned)v, src, 64);
+  const unsigned hi = __shfl((unsigned)(v >> 32), src, 64);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float fload(const float* p) {   // L2-served load of a cell another lane may have just written
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// place `item` at `pos` and let it rise (utils/heapq.py:9-21 with startpos = 0)
+__device__ __forceinline__ void coop_siftdown(u64* H, int pos, u64 item, int lane) {
+  const unsigned q = (unsigned)pos + 1u;
+  const int depth = 31 - __clz(q);                // number of ancestors (< 31)
+  const int sh = lane < 31 ? lane : 30;           // lanes >= depth are idle; keep their shifts defined
+  const int my_dst = (int)(q >> sh) - 1;          // lane L: position of ancestor L-1 (L = 0: pos itself)
+  const int my_anc = (int)(q >> (sh + 1)) - 1;    // lane L: position of ancestor L
+  u64 anc = 0;
+  if (lane < depth) anc = hload(H + my_anc);
+  const bool rises = (lane < depth) && (item_key(item) < item_key(anc));
+  const u64 mask = __ballot(rises);
+  const int m = (mask == ~0ull) ? 64 : __builtin_ctzll(~mask);  // item passes ancestors 0 .. m-1
+  if (lane < m) hstore(H + my_dst, anc);
+  else if (lane == m) hstore(H + my_dst, item);
+}
+
+// sibling's value through DPP (lane ^ 1): pure VALU, no LDS crossbar
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int dpp_xor1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+
+// utils/heapq.py:51-59 (+ :24-42): the bubble-up part of heappop after `last` was taken off the end
+// (n = remaining size >= 1).  Returns the leaf position where `last` has to be placed.
+__device__ __forceinline__ int coop_bubble(u64* H, int n, int lane) {
+  int pos = 0;  // the hole
+  const int lvl = 31 - __clz((unsigned)lane | 1u);
+  const int off = lane - (1 << lvl);
+  const u64 kInf = (u64)0x7f800000u << 32;
+  for (;;) {
+    // subtree under the hole: local node `lane` (1..63) <-> global index g
+    const long long g = (((long long)pos + 1) << lvl) - 1 + off;
+    const bool valid = (lane >= 1) && (g < (long long)n);
+    const u64 val = valid ? hload(H + g) : kInf;
+    const float key = item_key(val);
+    // "am I the child my parent bubbles up?"  children 2i (left, even lane) and 2i+1 (right, odd lane) are
+    // DPP neighbours.  heapq.py:33: take the right child iff it exists and not (left < right).
+    const float sib = dpp_xor1(key);
+    const int sib_valid = dpp_xor1_i((int)valid);
+    const bool is_right = lane & 1;
+    const bool right_wins = is_right ? (valid && !(sib < key)) : (sib_valid && !(key < sib));
+    const bool chosen = valid && (is_right ? right_wins : !right_wins);
+    const u64 W = __ballot(chosen && lane >= 2);
+    // walk the chosen-child bits from the subtree root (scalar code).  Exactly one of a node's two child
+    // bits is set while children exist; below a leaf every bit is 0, so the walk simply stops advancing.
+    int cur = 1;
+    u64 pathmask = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 5; ++s2) {
+      const int l = cur << 1;
+      const unsigned bits = (unsigned)(W >> l) & 3u;
+      if (bits) {
+        pathmask |= 1ull << cur;
+        cur = l + (int)(bits >> 1);
+      }
+    }
+    const int steps = __builtin_popcountll(pathmask);
+    // every inner lane knows its chosen child from W; the path nodes fetch that child's entry and store it
+    const int cl = (2 * lane) & 63;
+    const int nx = ((W >> cl) & 1ull) ? cl : cl + 1;
+    const u64 moved = shfl64(val, nx);
+    if ((pathmask >> lane) & 1ull) hstore(H + g, moved);
+    const int gcur = __builtin_amdgcn_readlane((int)g, cur);
+    pos = gcur;
+    if (steps < 5 || 2LL * gcur + 1 >= (long long)n) break;
+  }
+  return pos;
+}
+
+__global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) {
+  const long long b = blockIdx.x;
+  if (b >= p.B) return;
+  const int lane = threadIdx.x;
+  const int T = p.T, F = p.F;
+  const long long n = (long long)T * F;
+  float* spec = p.spec + b * n;
+  const float* tg = p.tgradw + b * n;
+  const float* fg = p.fgradw + b * n;
+  float* phase = p.phase + b * n;
+  u64* H = reinterpret_cast<u64*>(p.heap + b * (n + 2));
+  int* order = p.order ? p.order + b * n : nullptr;
+  const float abstol = p.abstol;
+
+  for (long long i = lane; i < n; i += 64) phase[i] = 0.0f;  // dgt.py:170
+
+  float max_val;
+  long long max_pos;
+  clip_argmax(spec, n, abstol, 0.f, false, lane, max_val, max_pos);  // :173-174
+  const float thr = max_val * p.tol;                                   // :177-178
+  long long npops = 0;
+  if (lane == 0) {
+    hstore(H, pack_item(-max_val, (int)max_pos));  // :175
+    spec[max_pos] = abstol;                         // :176
+  }
+  int hn = 1;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+  while (max_val > abstol) {  // :179
+    while (hn > 0) {          // :180
+      hn = uni(hn);
+      // heappop, part 1: take the last entry off, read the root (heapq.py:51-56)
+      const u64 last = hload(H + (hn - 1));
+      hn -= 1;
+      const u64 it = (hn == 0) ? last : hload(H);
+      const int c = uni(item_idx(it));
+      if (order && lane == 0) order[npops] = c;
+      ++npops;
+      const int col = c / F;        // frame
+      const int row = c - col * F;  // bin
+      // request the neighbourhood now (lanes 0..3: next frame, previous frame, next bin, previous bin,
+      // dgt.py:188-215); it does not depend on the heap repair below and arrives while that runs
+      const int d = (lane == 0) ? F : (lane == 1) ? -F : (lane == 2) ? 1 : -1;
+      const bool inb = (lane == 0) ? (col < T - 1) : (lane == 1) ? (col > 0) : (lane == 2) ? (row < F - 1)
+                                                                                            : (lane == 3) && (row > 0);
+      float s = 0.f, g_c = 0.f, g_n = 0.f, pc = 0.f;
+      if (lane < 4 && inb) {
+        const int nb = c + d;
+        const float* gr = (lane < 2) ? fg : tg;
+        s = fload(spec + nb);
+        g_c = gr[c];
+        g_n = gr[nb];
+        pc = fload(phase + c);
+      }
+      // heappop, part 2: bubble the smaller children up, drop `last` into the leaf, let it rise
+      if (hn > 0) {
+        const int leaf = coop_bubble(H, hn, lane);
+        coop_siftdown(H, leaf, last, lane);
+      }
+      const bool lv = (lane < 4) && inb && live(s, abstol, thr);
+      if (lv) {
+        const int nb = c + d;
+        const float half = (g_c + g_n) / 2.0f;
+        phase[nb] = (lane & 1) ? pc - half : pc + half;
+        spec[nb] = abstol;
+      }
+      const u64 lvmask = __ballot(lv);
+      const u64 mine = pack_item(-s, c + d);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((lvmask >> q) & 1ull) {
+          const u64 item = readlane64(mine, q);
+          coop_siftdown(H, hn, item, lane);  // heappush (heapq.py:45-48)
+          ++hn;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // the scan below must not hit stale L1 lines
+    // :216-219 reseed from the global max of what is left (lane-parallel scan)
+    clip_argmax(spec, n, abstol, thr, true, lane, max_val, max_pos);
+    if (lane == 0) {
+      hstore(H, pack_item(-max_val, (int)max_pos));
       spec[max_pos] = abstol;
     }
     hn = 1;
@@ -495,7 +703,12 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
   GradParams g = {mag, spec, tg, fg, (long long)B, T, F, n_fft, hop, gamma, abstol};
   hipLaunchKernelGGL(pghi_grad_offline_kernel, dim3(grid1d((long long)B * T * F)), dim3(256), 0, s, g);
   HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, order_or_null};
-  hipLaunchKernelGGL(pghi_hgi_offline_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
+  // ACIDS_PGHI_SERIAL=1 selects the single-lane reference kernel (debugging aid; identical results)
+  static const bool serial = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
+  if (serial)
+    hipLaunchKernelGGL(pghi_hgi_offline_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
+  else
+    hipLaunchKernelGGL(pghi_hgi_offline_coop_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
