@@ -623,6 +623,125 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_kernel(RtParams p) {
   for (long long i = lane; i < (long long)p.n * F; i += 64) p.phase_out[(long long)s * p.n * F + i] = phase[2LL * F + i];
 }
 
+// Same algorithm with the per-frame state in LDS: a frame's heap holds at most ~2F entries and touches only
+// two rows of each array, so the whole frame step runs out of the CU's LDS (one wave per stream, F <= 1025).
+__global__ __launch_bounds__(64) void pghi_hgi_rt_lds_kernel(RtParams p) {
+  extern __shared__ __attribute__((aligned(16))) float rt_smem[];
+  const int s = blockIdx.x;
+  if (s >= p.S) return;
+  const int lane = threadIdx.x;
+  const int F = p.F, R = p.n + 2;
+  const long long n = (long long)R * F;
+  const float* spec = p.spec + (long long)s * n;
+  const float* tgw = p.tgradw + (long long)s * n;
+  const float* fgw = p.fgradw + (long long)s * n;
+  float* phase = p.phase + (long long)s * n;
+  float* srow = rt_smem;       // working copy of spectrogram row f
+  float* hrow = srow + F;      // untouched row f-1 (spectrogram_history, dgt.py:411)
+  float* ph0 = hrow + F;       // phase row f-1
+  float* ph1 = ph0 + F;        // phase row f
+  float* tg0 = ph1 + F;        // padded tgradw rows f-1 and f  (= rows f-3, f-2 of the unpadded array, or 0)
+  float* tg1 = tg0 + F;
+  float* fg1 = tg1 + F;        // padded fgradw row f
+  HeapItem* heap = reinterpret_cast<HeapItem*>(fg1 + F + (F & 1));
+
+  float smax = -1.0f;
+  for (long long i = lane; i < n; i += 64) smax = fmaxf(smax, spec[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+  float abstol = p.tol * smax;  // :400
+  if (abstol < p.eps) abstol = p.eps;
+
+  for (int k = lane; k < F; k += 64) {  // :402-403 rows 0 and 1 of the phase array
+    phase[k] = 0.0f;
+    phase[F + k] = p.prev_phase[(long long)s * F + k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+
+  for (int f = 2; f < R; ++f) {  // :413
+    float max_val = -1.0f;
+    long long max_k = F;
+    for (int k = lane; k < F; k += 64) {
+      const float v = spec[(long long)f * F + k];
+      srow[k] = v;
+      hrow[k] = spec[(long long)(f - 1) * F + k];
+      ph0[k] = phase[(long long)(f - 1) * F + k];
+      ph1[k] = (v > abstol) ? 0.0f : p.noise[(long long)s * p.n * F + (long long)(f - 2) * F + k];  // :404-405
+      tg0[k] = (f - 1 >= 2) ? tgw[(long long)(f - 3) * F + k] : 0.0f;  // :408-410 two-row front padding
+      tg1[k] = tgw[(long long)(f - 2) * F + k];
+      fg1[k] = fgw[(long long)(f - 2) * F + k];
+      if (v > max_val) {
+        max_val = v;
+        max_k = k;
+      }
+    }
+    wave_argmax(max_val, max_k);
+    __syncthreads();
+    if (max_val > abstol && lane == 0) {  // :416-417
+      int hn = 0;
+      heap[0].key = -max_val;  // :427 the seed is NOT marked visited
+      heap[0].idx = F + (int)max_k;  // idx = (row == f ? F : 0) + bin
+      hn = 1;
+      for (int k = 0; k < F; ++k) {  // :428-430
+        const float hv = hrow[k];
+        if (hv > abstol) h_push(heap, hn, -hv, k);
+      }
+      while (max_val > abstol) {  // :433
+        while (hn > 0) {
+          const HeapItem it = h_pop(heap, hn);
+          const bool cur_row = it.idx >= F;
+          const int k = cur_row ? it.idx - F : it.idx;
+          if (!cur_row) {  // :436-443 propagate in time
+            const float sv = srow[k];
+            if (sv > abstol) {
+              ph1[k] = ph0[k] + 0.5f * (tg0[k] + tg1[k]);
+              h_push(heap, hn, -sv, F + k);
+              srow[k] = abstol;
+            }
+          } else {  // :444-460 propagate in frequency
+            if (k + 1 < F) {
+              const float sv = srow[k + 1];
+              if (sv > abstol) {
+                ph1[k + 1] = ph1[k] + 0.5f * (fg1[k] + fg1[k + 1]);
+                h_push(heap, hn, -sv, F + k + 1);
+                srow[k + 1] = abstol;
+              }
+            }
+            if (k - 1 > 0) {  // bin 0 is never reached downward (:453)
+              const float sv = srow[k - 1];
+              if (sv > abstol) {
+                ph1[k - 1] = ph1[k] - 0.5f * (fg1[k] + fg1[k - 1]);
+                h_push(heap, hn, -sv, F + k - 1);
+                srow[k - 1] = abstol;
+              }
+            }
+          }
+        }
+        // :461-465 reseed inside the frame
+        max_val = srow[0];
+        int mk = 0;
+        for (int k = 1; k < F; ++k)
+          if (srow[k] > max_val) {
+            max_val = srow[k];
+            mk = k;
+          }
+        h_push(heap, hn, -max_val, F + mk);
+        srow[mk] = abstol;
+      }
+    }
+    __syncthreads();
+    for (int k = lane; k < F; k += 64) {
+      const float v = ph1[k];
+      phase[(long long)f * F + k] = v;
+      p.phase_out[(long long)s * p.n * F + (long long)(f - 2) * F + k] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __syncthreads();
+  }
+}
+
 // x = mag * exp(i phase): refresh the PGHI history (|x[-2:]|, angle(x[-1]))   dgt.py:325-336
 struct RtUpdParams {
   const float* mag;       // (S, n, F)
@@ -737,7 +856,11 @@ int at_pghi_realtime(const float* mag_hist, const float* mag, const float* prev_
   p.S = S; p.n = n; p.F = F; p.n_fft = n_fft; p.hop = hop; p.gamma = gamma; p.tol = tol; p.eps = eps;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pghi_grad_rt_kernel, dim3(grid1d((long long)S * per)), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(pghi_hgi_rt_kernel, dim3((unsigned)S), dim3(64), 0, s, p);
+  const size_t lds = sizeof(float) * (7 * (size_t)F + 1) + sizeof(HeapItem) * (4 * (size_t)F + 8);
+  if (lds <= 64 * 1024)
+    hipLaunchKernelGGL(pghi_hgi_rt_lds_kernel, dim3((unsigned)S), dim3(64), lds, s, p);
+  else
+    hipLaunchKernelGGL(pghi_hgi_rt_kernel, dim3((unsigned)S), dim3(64), 0, s, p);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 

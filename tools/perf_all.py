@@ -58,3 +58,19 @@ if "pghi" in which:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("pghi B=%d  %.3f s  %.1f kframes/s  %.2f Mpops/s" % (nb, dt, nb * T / dt / 1e3, nb * T * 513 / dt / 1e6))
+if "rt" in which:
+    import time
+    S, nfr = 256, int(os.environ.get("RT_FRAMES", "16"))
+    rt = A.RealtimeDGT(batch_size=[S]).to(dev)
+    fr = torch.randn(S, nfr, 1024, device=dev) * 0.1
+    Xr = rt(fr)
+    mg = Xr.abs()
+    rt.invert(mg, inversion_mode="pghi")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        rt.invert(mg, inversion_mode="pghi")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print("rtpghi S=%d n=%d  %.2f ms per step  %.1f kframes/s  (real-time budget %.1f ms)" % (
+        S, nfr, dt * 1e3, S * nfr / dt / 1e3, nfr * 256 / 44.1))
