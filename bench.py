@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the all-gather / PGHI side measurements")
-    ap.add_argument("--pghi-clips", type=int, default=256)
+    ap.add_argument("--pghi-clips", type=int, default=1024, help="clips for the DGT+PGHI round-trip side measurement")
+    ap.add_argument("--streams", type=int, default=256, help="concurrent streams for the RealtimeDGT side measurement")
     return ap.parse_args()
 
 
@@ -101,11 +102,18 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no ROCm device: bench.py measures the HIP path only"}))
         sys.exit(2)
+    rehearsal = os.environ.get("ACIDS_BENCH_REHEARSAL") == "1"   # dev only: N ranks share cuda:0 over gloo
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev
     import acids_transforms_amd as A
     from acids_transforms_amd import ops
 
@@ -162,7 +170,7 @@ def main():
         ktimes["mel"].append(e[1].elapsed_time(e[2]))
         ktimes["istft"].append(e[2].elapsed_time(e[3]))
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -196,7 +204,7 @@ def main():
     extras = {}
     if not args.no_extras:
         # (a) features reassembled on every rank with one RCCL all-gather, overlapped with the next step's compute
-        if world > 1:
+        if world > 1 and not rehearsal:
             from acids_transforms_amd.dist import all_gather_features
             comm = torch.cuda.Stream(device=dev)
             torch.cuda.synchronize()
@@ -221,20 +229,41 @@ def main():
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             extras["with_feature_allgather_frames_per_s"] = world * frames_per_step * args.steps / float(tt.item())
-        # (b) BASELINE config 3: DGT + PGHI invert round trip, dense noise (worst case: every bin above tolerance)
+        # (b) BASELINE config 3: DGT + PGHI invert round trip, dense noise (worst case: every bin above
+        #     tolerance).  One wave per clip, latency-bound: throughput grows with the number of clips in flight.
         if rank == 0 and args.pghi_clips > 0:
             dgt = A.DGT(sr=SR, n_fft=N_FFT, hop_length=HOP).to(dev)
-            pb = min(args.pghi_clips, B)
-            m = dgt(x[:pb]).abs()
+            pg = {}
+            for nb in sorted({min(args.pghi_clips, B), min(4 * args.pghi_clips, 4096)}):
+                xs = x if nb <= B else torch.randn(nb, CLIP_LEN, device=dev, generator=gen) * 0.1
+                m = dgt(xs[:nb]).abs()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                yp = dgt.invert(m, inversion_mode="pghi")
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                pg["clips_%d" % nb] = {"frames_per_s": nb * T_FRAMES / dt, "seconds": dt,
+                                       "heap_pops_per_s": float(nb) * T_FRAMES * F_BINS / dt}
+                del m, yp, xs
+            pg["input"] = "|DGT(randn*0.1)|: ~100% of bins above tolerance; PGHI + polar ISTFT"
+            extras["pghi_invert"] = pg
+        # (c) BASELINE config 5 (streaming): RealtimeDGT fwd -> |.| -> RTPGHI -> irfft, one hop per step
+        if rank == 0 and args.streams > 0:
+            S = args.streams
+            rt = A.RealtimeDGT(sr=SR, n_fft=N_FFT, hop_length=HOP, batch_size=[S]).to(dev)
+            fr = torch.randn(S, 1, N_FFT, device=dev, generator=gen) * 0.1
+            for _ in range(3):
+                rt.invert(rt(fr).abs(), inversion_mode="pghi")
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            yp = dgt.invert(m, inversion_mode="pghi")
+            nst = 50
+            for _ in range(nst):
+                rt.invert(rt(fr).abs(), inversion_mode="pghi")
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            extras["pghi_invert"] = {"clips": pb, "frames_per_s": pb * T_FRAMES / dt, "seconds": dt,
-                                     "input": "|DGT(randn*0.1)|, ~100% of bins above tolerance",
-                                     "pops_per_s": pb * T_FRAMES * F_BINS / dt}
-            del m, yp
+            dt = (time.perf_counter() - t1) / nst
+            extras["realtime_dgt_step"] = {"streams": S, "ms_per_hop_step": dt * 1e3, "frames_per_s": S / dt,
+                                           "realtime_budget_ms": HOP / SR * 1e3,
+                                           "note": "eager launches (no hipGraph yet), fp32"}
         barrier()
 
     result = {
