@@ -86,17 +86,17 @@ class DGT(STFT):
         """Phase for a (T, F) or (B, T, F) magnitude array (reference dgt.py:156-162,
         applied clip by clip as at :137-141).  The caller's tensor is not modified."""
         self._follow(mag)
-        tol = float(self.tolerance if tolerance is None else tolerance)
+        tol = self._hostf("tolerance") if (tolerance is None or tolerance is self.tolerance) else float(tolerance)
         squeeze = mag.dim() == 2
         m = mag.unsqueeze(0) if squeeze else mag
-        phase = ops.pghi_offline(m, float(self.gamma), self._n_fft, self._hop, tol, float(self.eps))
+        phase = ops.pghi_offline(m, self._hostf("gamma"), self._n_fft, self._hop, tol, self._hostf("eps"))
         return phase[0] if squeeze else phase
 
     def modgabphasegrad(self, mag: torch.Tensor):
         """(tgradw, fgradw) of a clamped (T, F) magnitude array (reference dgt.py:222-236)."""
         self._follow(mag)
         m = mag.unsqueeze(0) if mag.dim() == 2 else mag
-        tg, fg = ops.pghi_gradients(m, float(self.gamma), self._n_fft, self._hop)
+        tg, fg = ops.pghi_gradients(m, self._hostf("gamma"), self._n_fft, self._hop, self._hostf("eps"))
         return (tg[0], fg[0]) if mag.dim() == 2 else (tg, fg)
 
     def test_inversion(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -192,7 +192,7 @@ class RealtimeDGT(DGT):
         two-frame magnitude history and the previous phase.  `noise` (same shape as mag)
         overrides the standard-normal draws used for bins at or below the tolerance."""
         self._follow(mag)
-        tol = float(self.tolerance if tolerance is None else tolerance)
+        tol = self._hostf("tolerance") if (tolerance is None or tolerance is self.tolerance) else float(tolerance)
         m, batch_shape = reshape_batches(mag, -2)
         hist, _ = reshape_batches(self.hgi_mag_buffer, -2)
         prev, _ = reshape_batches(self.hgi_phase_buffer, -1)
@@ -200,8 +200,8 @@ class RealtimeDGT(DGT):
             noise = torch.randn_like(m)
         else:
             noise, _ = reshape_batches(noise, -2)
-        phase = ops.pghi_realtime(hist, m, prev, noise, float(self.gamma), self._n_fft, self._hop, tol,
-                                  float(self.eps))
+        phase = ops.pghi_realtime(hist, m, prev, noise, self._hostf("gamma"), self._n_fft, self._hop, tol,
+                                  self._hostf("eps"))
         return phase.reshape(batch_shape + phase.shape[1:])
 
     def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):

@@ -148,6 +148,18 @@ class STFT(AudioTransform):
         return ["griffin_lim", "keep_input", "random", "sinebank"]
 
     # -- device / state plumbing ----------------------------------------------
+    def _hostf(self, name: str) -> float:
+        """Python float of a scalar buffer (gamma, eps, tolerance) without a device sync per call:
+        the value is re-read only when the buffer object or its version counter changed."""
+        t = getattr(self, name)
+        key = (t.data_ptr(), t._version)
+        cache = self.__dict__.setdefault("_hostf_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, float(t))
+            cache[name] = hit
+        return hit[1]
+
     def _follow(self, x: torch.Tensor):
         if self.window.device != x.device:
             self.to(x.device)

@@ -247,23 +247,29 @@ def main():
                 del m, yp, xs
             pg["input"] = "|DGT(randn*0.1)|: ~100% of bins above tolerance; PGHI + polar ISTFT"
             extras["pghi_invert"] = pg
-        # (c) BASELINE config 5 (streaming): RealtimeDGT fwd -> |.| -> RTPGHI -> irfft, one hop per step
+        # (c) BASELINE config 5 (streaming): chunk -> OverlapAdd frames -> RealtimeDGT -> |X| -> RTPGHI -> irfft ->
+        #     overlap-add, 1024-sample chunks (4 hops; the reference's streaming state needs chunks >= 768 samples),
+        #     eager launches vs one hipGraph replay per chunk
         if rank == 0 and args.streams > 0:
-            S = args.streams
-            rt = A.RealtimeDGT(sr=SR, n_fft=N_FFT, hop_length=HOP, batch_size=[S]).to(dev)
-            fr = torch.randn(S, 1, N_FFT, device=dev, generator=gen) * 0.1
-            for _ in range(3):
-                rt.invert(rt(fr).abs(), inversion_mode="pghi")
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            nst = 50
-            for _ in range(nst):
-                rt.invert(rt(fr).abs(), inversion_mode="pghi")
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / nst
-            extras["realtime_dgt_step"] = {"streams": S, "ms_per_hop_step": dt * 1e3, "frames_per_s": S / dt,
-                                           "realtime_budget_ms": HOP / SR * 1e3,
-                                           "note": "eager launches (no hipGraph yet), fp32"}
+            from acids_transforms_amd.streaming import StreamingDGTSession
+            S, C = args.streams, 1024
+            chunk = torch.randn(S, C, device=dev, generator=gen) * 0.1
+            rtres = {"streams": S, "chunk_samples": C, "realtime_budget_ms": C / SR * 1e3}
+            for tag, use_graph in (("eager", False), ("hipgraph", True)):
+                sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=use_graph)
+                for _ in range(3):
+                    sess.step(chunk)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nst = 50
+                for _ in range(nst):
+                    sess.step(chunk)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / nst
+                rtres["ms_per_chunk_" + tag] = dt * 1e3
+                rtres["frames_per_s_" + tag] = S * (C // HOP) / dt
+                del sess
+            extras["realtime_dgt_stream"] = rtres
         barrier()
 
     result = {
