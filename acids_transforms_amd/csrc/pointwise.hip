@@ -143,6 +143,34 @@ __global__ void oadd_invert_kernel(const float* __restrict__ frames, const float
   }
 }
 
+// Griffin-Lim phase update (torchaudio.functional.griffinlim as called at reference stft.py:174-178):
+//   angles = rebuilt - momentum' * tprev;  angles /= (|angles| + 1e-16);  X = mag * angles
+// tprev == nullptr on the first iteration (the reference starts from tprev = 0).
+__global__ void griffinlim_update_kernel(const float* __restrict__ mag, const float2* __restrict__ rebuilt,
+                                         const float2* __restrict__ tprev, float mom, long long n,
+                                         float2* __restrict__ X) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float2 a = rebuilt[i];
+    if (tprev) {
+      const float2 t = tprev[i];
+      a.x -= mom * t.x;
+      a.y -= mom * t.y;
+    }
+    const float d = hypotf(a.x, a.y) + 1e-16f;
+    const float m = mag[i];
+    X[i] = make_float2(m * (a.x / d), m * (a.y / d));
+  }
+}
+
+// X = mag * z for a complex z (initial random "angles")
+__global__ void scale_complex_kernel(const float* __restrict__ mag, const float2* __restrict__ z, long long n,
+                                     float2* __restrict__ X) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float m = mag[i];
+    X[i] = make_float2(m * z[i].x, m * z[i].y);
+  }
+}
+
 static inline unsigned grid_for(long long n, int block) {
   long long b = (n + block - 1) / block;
   if (b > 256 * 8) b = 256 * 8;  // grid-stride above 8 blocks per CU
@@ -182,6 +210,26 @@ int at_stats(const void* A, int a_kind, int64_t n, int contrast, float eps, doub
   hipLaunchKernelGGL(stats_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace,
                      (int)blocks, out4);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+int at_griffinlim_update(const float* mag, const float* rebuilt_complex, const float* tprev_complex_or_null,
+                         float momentum_over_1p, int64_t n, float* X_complex, void* stream) {
+  if (n < 0) return AT_EINVAL;
+  if (n == 0) return AT_OK;
+  if (!mag || !rebuilt_complex || !X_complex) return AT_EINVAL;
+  hipLaunchKernelGGL(griffinlim_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, mag,
+                     (const float2*)rebuilt_complex, (const float2*)tprev_complex_or_null, momentum_over_1p, (long long)n,
+                     (float2*)X_complex);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+int at_scale_complex(const float* mag, const float* z_complex, int64_t n, float* X_complex, void* stream) {
+  if (n < 0) return AT_EINVAL;
+  if (n == 0) return AT_OK;
+  if (!mag || !z_complex || !X_complex) return AT_EINVAL;
+  hipLaunchKernelGGL(scale_complex_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, mag,
+                     (const float2*)z_complex, (long long)n, (float2*)X_complex);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 

@@ -351,3 +351,23 @@ def argmax_last(x):
     out = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
     check(lib().at_argmax_last(ptr(xi), ptr(xf), x.numel() // cols, cols, ptr(out), stream_ptr()), "at_argmax_last")
     return out
+
+
+def scale_complex(mag, z):
+    """mag (real) * z (complex64), same shape -> complex64."""
+    require_device(mag, z)
+    mag = _f32c(mag)
+    z = z if z.is_contiguous() else z.contiguous()
+    out = torch.empty(mag.shape, dtype=torch.complex64, device=mag.device)
+    check(lib().at_scale_complex(ptr(mag), ptr(z), mag.numel(), ptr(out), stream_ptr()), "at_scale_complex")
+    return out
+
+
+def griffinlim_update(mag, rebuilt, tprev, momentum_over_1p):
+    """One Griffin-Lim phase update: mag * normalise(rebuilt - m * tprev) -> complex64."""
+    require_device(mag, rebuilt)
+    mag = _f32c(mag)
+    out = torch.empty(mag.shape, dtype=torch.complex64, device=mag.device)
+    check(lib().at_griffinlim_update(ptr(mag), ptr(rebuilt), ptr(tprev), momentum_over_1p, mag.numel(), ptr(out),
+                                     stream_ptr()), "at_griffinlim_update")
+    return out

@@ -76,7 +76,9 @@ class DGT(STFT):
             phase = self.pghi(x, self.tolerance)
         elif inversion_mode == "random":
             phase = torch.pi * 2 * torch.rand_like(x)
-        elif inversion_mode in ("griffin_lim", "sinebank"):
+        elif inversion_mode == "griffin_lim":
+            return self.griffin_lim(x)
+        elif inversion_mode == "sinebank":
             raise NotImplementedError(_NOT_HOT_PATH % (inversion_mode, ", 'pghi'"))
         else:
             raise ValueError("inversion mode %s not valid." % self.inversion_mode)

@@ -252,9 +252,32 @@ class STFT(AudioTransform):
         if inversion_mode == "random":
             phase = torch.pi * 2 * torch.rand_like(x)
             return self._istft(mag=x, phase=phase)
-        if inversion_mode in ("griffin_lim", "sinebank"):
+        if inversion_mode == "griffin_lim":
+            return self.griffin_lim(x)
+        if inversion_mode == "sinebank":
             raise NotImplementedError(_NOT_HOT_PATH % (inversion_mode, ""))
         raise ValueError("inversion mode %s not valid." % inversion_mode)
+
+    def griffin_lim(self, x: torch.Tensor, n_iter: int = 30, momentum: float = 0.99,
+                    angles0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Griffin-Lim inversion of a (B, T, F) magnitude spectrogram with the synthesis window, 30 iterations,
+        momentum 0.99 and random initialisation -- the arguments the reference passes to
+        torchaudio.functional.griffinlim (stft.py:174-178).  A composition of the ISTFT and STFT kernels plus
+        one fused phase-update kernel per iteration.  `angles0` (complex, same shape) overrides the random start."""
+        n, h = self._n_fft, self._hop
+        window = self.inv_window[:n]
+        m = momentum / (1 + momentum)
+        if angles0 is None:
+            angles0 = torch.rand(x.shape, dtype=torch.complex64, device=x.device)
+        env = self._env16 if self._env16.numel() else None
+        X = ops.scale_complex(x, angles0)
+        tprev = None
+        for _ in range(n_iter):
+            inverse = ops.istft(X, window, n, h, env16=env)
+            rebuilt = ops.stft_forward(inverse, window, n, h, center=True)
+            X = ops.griffinlim_update(x, rebuilt, tprev, m)
+            tprev = rebuilt
+        return ops.istft(X, window, n, h, env16=env)
 
     # -- self tests (same hooks as the reference) -------------------------------
     def test_inversion(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:

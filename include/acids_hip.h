@@ -147,6 +147,14 @@ int at_rt_update_buffers(const float *mag, const float *phase, int S, int n, int
  * and hgi_phase_buffer of dgt.py:336. */
 int at_angle(const float *x_complex, int64_t n, float *out, void *stream);
 
+/* ---- Griffin-Lim building blocks (STFT's default inversion mode, stft.py:37,174-178) ---- */
+/* One phase update of torchaudio.functional.griffinlim:  a = rebuilt - m*tprev (tprev may be NULL);
+ * X = mag * a / (|a| + 1e-16), with m = momentum / (1 + momentum).  n complex elements. */
+int at_griffinlim_update(const float *mag, const float *rebuilt_complex, const float *tprev_complex_or_null,
+                         float momentum_over_1p, int64_t n, float *X_complex, void *stream);
+/* X = mag * z (z complex): the random initialisation of the same algorithm. */
+int at_scale_complex(const float *mag, const float *z_complex, int64_t n, float *X_complex, void *stream);
+
 /* ---- K6/K7: OverlapAdd streaming framer / overlap-add ---------------------- */
 /* OverlapAdd.forward (oadd.py:69-74, 33-42): buf (S, buf_len) = [history | chunk | 0...],
  * hist_out = last `keep` samples of [history | chunk].  The caller takes the

@@ -157,3 +157,25 @@ def test_full_size_properties(dev):
 def test_fails_loudly_on_cpu_tensor():
     with pytest.raises(A.AcidsHipError):
         A.STFT()(torch.randn(2, 4096))
+
+
+def test_griffin_lim(dev):
+    """STFT's default inversion mode: same algorithm as the oracle restatement from identical starting angles;
+    and with the random start the resynthesis' magnitudes converge to the target (spectral convergence)."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 6000, generator=g) * 0.1
+    m = A.STFT().to(dev)
+    assert m.inversion_mode == "griffin_lim"
+    mag = m(x.to(dev)).abs()
+    a0 = torch.rand(mag.shape, dtype=torch.complex64, generator=g)
+    y = m.griffin_lim(mag, n_iter=5, angles0=a0.to(dev))
+    yr = O.griffinlim(mag.cpu(), O.hann_window(1024), 1024, 256, a0, n_iter=5)
+    assert y.shape == yr.shape
+    assert rel_max(cpu(y), yr.numpy()) < 2e-4          # 5 nonlinear iterations amplify fp32 round-off
+    y30 = m.invert(mag)                                 # default mode, 30 iterations, random start
+    assert y30.shape == (2, 5888) and bool(torch.isfinite(y30).all())
+    mag30 = m(torch.nn.functional.pad(y30, (0, 6000 - 5888))).abs()
+    sc = float((mag30[:, 2:-3] - mag[:, 2:-3]).norm() / mag[:, 2:-3].norm())
+    assert sc < 0.35, sc
+    d = A.DGT(inversion_mode="griffin_lim").to(dev)
+    assert d.invert(d(x.to(dev)).abs()).shape == (2, 5888)
