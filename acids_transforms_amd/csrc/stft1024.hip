@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void stft1024_h256_fwd_kernel(FwdRu
   // branch-free loop: two unconditional 8-byte loads issued *before* this frame's stores, so the
   // compiler's vmcnt accounting lets the stores stay in flight across iterations.
   long long t = t0;
-  long long t_fast_end = (L - 768) / 256 + 1;          // first t for which the successor needs reflection
+  long long t_fast_end = (L >= 768) ? (L - 768) / 256 + 1 : 0;   // first t whose successor needs reflection
   if (t_fast_end > t1 - 1) t_fast_end = t1 - 1;        // the last frame of the run has no successor to fetch
   if (!clip_aligned) t_fast_end = t0;                  // odd-length clips: generic loop only
   if (t < t_fast_end) {
