@@ -140,14 +140,36 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stft1024_fwd_kernel(FwdP
 // shifted by two slots per frame, and only the 256 new samples (two 8-byte loads
 // per lane) are fetched per frame -- 1 KB of loads per frame instead of 4 KB.
 // ---------------------------------------------------------------------------
+// Banded filterbank for the fused |X| -> mel epilogue: filter n has its non-zero weights in
+// rows [start[n], start[n]+len[n]) of the (F x N) bank, stored row-major in wT[n][0..lpad).
+// slot[q*64 + lane] = filter handled by `lane` in pass q (-1 = none); long and short filters are paired.
+struct BandBank {
+  const int* start;
+  const int* len;
+  const int* slot;
+  const float* wT;
+  int n_filters, lpad, n_slots;
+  int slot_len[4];   // longest band in each pass, rounded up to a multiple of 4 (<= lpad)
+};
+constexpr int kMaxBandFloats = 4096;   // LDS copy of the band weights (n_filters * lpad floats, 16 KB)
+
 struct FwdRunParams {
   const float* x;
   const float* window;
   const float2* tw;
-  float2* out;
+  float2* out;     // may be null when only the features are wanted (MEL == 2)
   float* phase;
   long long B, L, clip_stride, T;
   long long runs_per_clip, frames_per_run;
+  // fused magnitude / mel epilogue (MEL != 0)
+  BandBank bank;
+  float* feat;            // (B*T, N) or, with feat_channel_major, (B, N, T)
+  const float* offset;    // device scalars or null
+  const float* scale;
+  float eps;
+  int contrast;           // 0 none, 1 log1p, 2 log, 3 log10
+  int power2;             // |X|^2 instead of |X|
+  int feat_channel_major;
 };
 
 // element n = lane + 64 m of the frame starting at padded position p0 (original index p0 - 512 + 2n)
@@ -163,9 +185,19 @@ __device__ __forceinline__ float2 load_pair(const float* clip, long long L, long
 
 constexpr int FWD_WAVES = 4;  // 5 x 4.5 KB slabs + 15 KB tables = 37.7 KB -> 4 blocks = 20 waves per CU
 
-template <bool WRITE_PHASE>
-__global__ __launch_bounds__(64 * FWD_WAVES) void stft1024_h256_fwd_kernel(FwdRunParams p) {
-  __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTwiddleCount + 512];
+__device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
+  switch (mode) {
+    case 1: return logf(1.0f + v);
+    case 2: return logf(fmaxf(v, eps));
+    case 3: return log10f(fmaxf(v, eps));
+    default: return v;
+  }
+}
+
+// MEL: 0 = spectrum only; 1 = spectrum + fused banded-filterbank features; 2 = features only
+template <bool WRITE_PHASE, int MEL>
+__global__ __launch_bounds__(64 * FWD_WAVES, 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
+  __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTwiddleCount + 512 + (MEL ? kMaxBandFloats / 2 : 0)];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
@@ -174,6 +206,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void stft1024_h256_fwd_kernel(FwdRu
   for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * FWD_WAVES) tab[i] = p.tw[i];
   for (int i = threadIdx.x; i < 512; i += 64 * FWD_WAVES)
     tab[kTwiddleCount + i] = reinterpret_cast<const float2*>(p.window)[i];
+  float* wlds = reinterpret_cast<float*>(tab + kTwiddleCount + 512);   // band weights, workgroup-shared
+  if (MEL != 0)
+    for (int i = threadIdx.x; i < p.bank.n_filters * p.bank.lpad; i += 64 * FWD_WAVES) wlds[i] = p.bank.wT[i];
   __syncthreads();
 
   const long long run = (long long)blockIdx.x * FWD_WAVES + wave;
@@ -211,6 +246,23 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void stft1024_h256_fwd_kernel(FwdRu
   for (int m = 0; m < 8; ++m) asm volatile("" : "+v"(raw[m].x), "+v"(raw[m].y));
   float2* row = p.out + (b * p.T + t0) * F;
   float* prow = WRITE_PHASE ? p.phase + (b * p.T + t0) * F : nullptr;
+  float* frow = (MEL != 0) ? p.feat + (b * p.T + t0) * (long long)p.bank.n_filters : nullptr;
+  long long t_cur = t0;
+  float mel_off = 0.f, mel_sc = 1.f;
+  if (MEL != 0 && p.offset) {
+    mel_off = *p.offset;
+    mel_sc = *p.scale;
+  }
+  // this lane's filters (one per pass): index, first bank row, LDS offset of its weights -- loop invariant
+  int mel_f[4] = {-1, -1, -1, -1}, mel_st[4] = {0, 0, 0, 0};
+  if (MEL != 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < p.bank.n_slots) {
+        mel_f[q] = p.bank.slot[q * 64 + lane];
+        mel_st[q] = p.bank.start[mel_f[q] >= 0 ? mel_f[q] : 0];
+      }
+  }
 
   // one frame: window, FFT, merge, store; `n6`/`n7` are the next frame's two new segments, already requested.
   // The Nyquist bin (a one-lane, exec-masked store the compiler cannot count on) is deferred to the top of the
@@ -237,15 +289,57 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void stft1024_h256_fwd_kernel(FwdRu
     fft512<false>(v, tw, lds, lane);
     float2 nyq;
     rfft_merge(v, tw, lane, nyq);
+    if (MEL != 2) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) row[lane + 64 * m] = v[m];
+      for (int m = 0; m < 8; ++m) row[lane + 64 * m] = v[m];
+    }
     if (WRITE_PHASE) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) prow[lane + 64 * m] = atan2f(v[m].y, v[m].x);
       prow += F;
     }
+    if (MEL != 0) {
+      // |X| (or |X|^2) of this frame into the wave's LDS slab (free again after the FFT), then every lane
+      // gathers the bands of its filters: sum_k |X[k]| w[k][n] over the band only (the rest of the column is 0)
+      float* absrow = reinterpret_cast<float*>(lds);
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float s2 = fmaf(v[m].x, v[m].x, v[m].y * v[m].y);
+        absrow[lane + 64 * m] = p.power2 ? s2 : __builtin_amdgcn_sqrtf(s2);
+      }
+      // bin 512, then zeros: a band walk may run up to lpad - 1 entries past its filter (zero weights there)
+      absrow[512 + lane] = (lane == 0) ? (p.power2 ? nyq.x * nyq.x : fabsf(nyq.x)) : 0.0f;
+      absrow[576 + lane] = 0.0f;
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q >= p.bank.n_slots) break;
+        const int f = mel_f[q];
+        const int fs = f >= 0 ? f : 0;
+        const float* a = absrow + mel_st[q];
+        const float* w = wlds + fs * p.bank.lpad;
+        float acc = 0.f;
+        const int steps = p.bank.slot_len[q];            // wave-uniform; shorter bands multiply zeros
+        for (int j = 0; j < steps; j += 4) {
+          acc = fmaf(a[j], w[j], acc);
+          acc = fmaf(a[j + 1], w[j + 1], acc);
+          acc = fmaf(a[j + 2], w[j + 2], acc);
+          acc = fmaf(a[j + 3], w[j + 3], acc);
+        }
+        if (f >= 0) {
+          acc = fwd_contrast(acc, p.contrast, p.eps);
+          if (p.offset) acc = (acc - mel_off) / mel_sc;
+          if (p.feat_channel_major) p.feat[((long long)b * p.bank.n_filters + f) * p.T + t_cur] = acc;
+          else frow[f] = acc;
+        }
+      }
+      wave_lds_sync();
+      frow += p.bank.n_filters;
+      ++t_cur;
+    }
     nyq_pending = nyq;
-    nyq_dst = row + 512;
+    nyq_dst = (MEL != 2) ? row + 512 : nullptr;
     row += F;
   };
 
@@ -487,13 +581,19 @@ int launch_stft1024_fwd(const float* x, long long B, long long L, long long clip
 }
 
 int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long clip_stride, long long T,
-                             const float* window, const float2* tw, float2* out, float* phase, hipStream_t stream) {
-  FwdRunParams p;
+                             const float* window, const float2* tw, float2* out, float* phase, const BandBank* bank,
+                             float* feat, const float* offset, const float* scale, float eps, int contrast, int power2,
+                             int feat_channel_major, hipStream_t stream) {
+  FwdRunParams p = {};
   p.x = x; p.window = window; p.tw = tw; p.out = out; p.phase = phase;
   p.B = B; p.L = L; p.clip_stride = clip_stride; p.T = T;
+  if (bank) {
+    p.bank = *bank; p.feat = feat; p.offset = offset; p.scale = scale; p.eps = eps; p.contrast = contrast;
+    p.power2 = power2; p.feat_channel_major = feat_channel_major;
+  }
   if (B * T == 0) return 0;
   // ~16 waves per CU; runs of at least 24 frames so that the 3 extra segment loads of a run start stay < 5 %
-  long long target_waves = (long long)num_cus() * 20;
+  long long target_waves = (long long)num_cus() * 16;
   long long runs_per_clip = (target_waves + B - 1) / B;
   if (runs_per_clip < 1) runs_per_clip = 1;
   long long fpr = (T + runs_per_clip - 1) / runs_per_clip;
@@ -504,10 +604,16 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   p.frames_per_run = fpr;
   long long waves = B * runs_per_clip;
   long long blocks = (waves + FWD_WAVES - 1) / FWD_WAVES;
-  if (phase)
-    hipLaunchKernelGGL(stft1024_h256_fwd_kernel<true>, dim3((unsigned)blocks), dim3(64 * FWD_WAVES), 0, stream, p);
-  else
-    hipLaunchKernelGGL(stft1024_h256_fwd_kernel<false>, dim3((unsigned)blocks), dim3(64 * FWD_WAVES), 0, stream, p);
+  const dim3 grid((unsigned)blocks), block(64 * FWD_WAVES);
+  if (!bank) {
+    if (phase) hipLaunchKernelGGL((stft1024_h256_fwd_kernel<true, 0>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((stft1024_h256_fwd_kernel<false, 0>), grid, block, 0, stream, p);
+  } else if (out) {
+    if (phase) hipLaunchKernelGGL((stft1024_h256_fwd_kernel<true, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((stft1024_h256_fwd_kernel<false, 1>), grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((stft1024_h256_fwd_kernel<false, 2>), grid, block, 0, stream, p);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -371,3 +371,24 @@ def griffinlim_update(mag, rebuilt, tprev, momentum_over_1p):
     check(lib().at_griffinlim_update(ptr(mag), ptr(rebuilt), ptr(tprev), momentum_over_1p, mag.numel(), ptr(out),
                                      stream_ptr()), "at_griffinlim_update")
     return out
+
+
+def stft_mel_forward(x, window, band, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1,
+                     want_spectrum=True, want_phase=False, channel_major=False):
+    """Fused n_fft=1024 / hop=256 forward: x (B, L) -> (X (B,T,513) complex64 or None, phase or None, features).
+    `band` is a utils.banded.BandedBank (eligible).  features: (B, T, N), or (B, N, T) when channel_major."""
+    require_device(x, window)
+    x = _f32c(x)
+    B, L = x.shape
+    T = 1 + L // 256
+    start, length, slot, wT = band.on(x.device)
+    N = band.N
+    X = torch.empty((B, T, 513), dtype=torch.complex64, device=x.device) if want_spectrum else None
+    phase = torch.empty((B, T, 513), dtype=torch.float32, device=x.device) if (want_phase and want_spectrum) else None
+    feat = torch.empty((B, N, T) if channel_major else (B, T, N), dtype=torch.float32, device=x.device)
+    check(lib().at_stft_mel_forward(ptr(x), B, L, L, T, 1024, 256, ptr(window), ptr(start), ptr(length), ptr(slot),
+                                    ptr(wT), N, band.lpad, band.n_slots, band.slot_len.ctypes.data,
+                                    contrast_code(contrast), int(power == 2),
+                                    ptr(offset), ptr(scale), eps, ptr(X), ptr(phase), ptr(feat), int(channel_major),
+                                    stream_ptr()), "at_stft_mel_forward")
+    return X, phase, feat

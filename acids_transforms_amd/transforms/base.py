@@ -128,8 +128,19 @@ class ComposeAudioTransform(AudioTransform):
             x = t(x)
 
     def forward(self, x: torch.Tensor):
-        for t in self.transforms:
+        stages = list(self.transforms)
+        i = 0
+        while i < len(stages):
+            t = stages[i]
+            nxt = stages[i + 1] if i + 1 < len(stages) else None
+            # STFT/DGT directly followed by a Magnitude with a banded (mel) bank runs as one fused kernel:
+            # same results, the spectrum is not read back from HBM
+            if nxt is not None and hasattr(nxt, "can_fuse_with") and nxt.can_fuse_with(t, x):
+                x = nxt.forward_fused(t, x)
+                i += 2
+                continue
             x = t(x)
+            i += 1
         return x
 
     def forward_with_time(self, x: torch.Tensor, time: torch.Tensor):

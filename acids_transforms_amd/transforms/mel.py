@@ -15,6 +15,7 @@ from typing import Union
 import torch
 
 from .. import ops
+from ..utils.banded import BandedBank
 from ..utils.melbank import melscale_fbanks
 from ..utils.misc import reshape_batches
 from .base import AudioTransform, NotInvertibleError
@@ -56,6 +57,7 @@ class MFCC(AudioTransform):
         fb = melscale_fbanks(n_fft // 2 + 1, 0.0, float(self.sr // 2), n_mels, self.sr)
         self.register_buffer("window", window.to(dev) if dev else window, persistent=False)
         self.register_buffer("fbank", fb.to(dev) if dev else fb, persistent=False)
+        self._band = BandedBank(fb)
         if self.n_mfcc is not None:
             n = torch.arange(float(n_mels))
             k = torch.arange(float(self.n_mfcc)).unsqueeze(1)
@@ -86,6 +88,15 @@ class MFCC(AudioTransform):
     def forward(self, x: torch.Tensor):
         self._follow(x)
         xb, batch_shape = reshape_batches(x, -1)
+        if (self.n_mfcc is None and self.n_fft == 1024 and self.hop_length == 256 and self._band.eligible
+                and xb.dtype == torch.float32 and xb.shape[-1] > 512 and not (xb.shape[-1] & 1)):
+            # one kernel, audio -> mel power: the spectrum never goes to HBM
+            off = sc = None
+            if self.norm is not None:
+                off, sc = self.norm._params(x)
+            _, _, mel = ops.stft_mel_forward(xb, self.window, self._band, None, off, sc, power=int(self.power),
+                                             want_spectrum=False, channel_major=True)
+            return mel.reshape(batch_shape + mel.shape[-2:])
         X = ops.stft_forward(xb, self.window, self.n_fft, self.hop_length, center=True)     # (B, T, F)
         T = X.shape[-2]
         off = sc = None

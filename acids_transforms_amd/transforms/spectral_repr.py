@@ -13,6 +13,7 @@ from typing import Union
 import torch
 
 from .. import ops
+from ..utils.banded import BandedBank
 from ..utils.melbank import melscale_fbanks
 from .base import AudioTransform, InversionEnumType
 from .norm import Normalize, stats_to_affine
@@ -82,6 +83,50 @@ class Magnitude(AudioTransform):
                                    % (tuple(self.norm.offset.shape),))
             return self.norm.offset, self.norm.scale
         return None, None
+
+    # -- fusion with the preceding STFT / DGT stage ---------------------------------------------
+    def _banded(self):
+        """Banded form of `mel_bank` for the fused forward kernel (None when the bank is not banded
+        enough, or when this module's options rule the fusion out); rebuilt when the buffer changes."""
+        if not self.mel or not self.keep_nyquist:
+            return None
+        bank = self.mel_bank
+        key = (bank.data_ptr(), bank._version)
+        cached = self.__dict__.get("_band_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, BandedBank(bank))
+            self.__dict__["_band_cache"] = cached
+        return cached[1] if cached[1].eligible else None
+
+    def can_fuse_with(self, stage, x: torch.Tensor) -> bool:
+        """True when `stage` (an offline STFT/DGT with n_fft=1024, hop=256) followed by this module can run
+        as the single fused kernel on input x."""
+        from .stft import STFT, RealtimeSTFT
+        from .dgt import RealtimeDGT
+        if not isinstance(stage, STFT) or isinstance(stage, (RealtimeSTFT, RealtimeDGT)):
+            return False
+        if stage._n_fft != 1024 or stage._hop != 256 or not x.is_cuda or x.dtype != torch.float32:
+            return False
+        if x.shape[-1] <= 512 or (x.shape[-1] & 1):
+            return False
+        ops.contrast_code(self.contrast_mode)
+        return self._banded() is not None
+
+    def forward_fused(self, stage, x: torch.Tensor, return_spectrum: bool = False):
+        """self(stage(x)) in one kernel; `stage` keeps its phase-buffer side effect.
+        return_spectrum=True also hands back stage(x) (it is written anyway): (X, features)."""
+        from ..utils.misc import reshape_batches
+        stage._follow(x)
+        self._follow(x)
+        off, sc = self._affine()
+        xb, batch_shape = reshape_batches(x, -1)
+        X, phase, feat = ops.stft_mel_forward(xb, stage.window[:1024], self._banded(), self.contrast_mode, off, sc,
+                                              self._eps, want_phase=stage.eager_phase)
+        stage._replace_phase_buffer(X, phase)
+        feat = feat.reshape(batch_shape + feat.shape[-2:])
+        if return_spectrum:
+            return X.reshape(batch_shape + X.shape[-2:]), feat
+        return feat
 
     def contrast(self, mag: torch.Tensor) -> torch.Tensor:
         ops.contrast_code(self.contrast_mode)   # TypeError on unknown modes, like the reference

@@ -54,6 +54,23 @@ int at_init(int device);
 int at_stft_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
                     int center, const float *window, float *out_complex, float *phase, void *stream);
 
+/* Fused forward for Compose(STFT|DGT -> Magnitude(mel)) and for MFCC (n_fft = 1024, hop = 256):
+ * the same framing + rFFT kernel additionally emits normalise(contrast(|X|^p @ bank)) from registers, so
+ * the spectrum is not re-read (spectral_repr.py:215-226 / mel.py:43-44,68-73 behind stft.py:98-104).
+ * The bank is passed in banded form: filter n has its non-zero rows in [band_start[n], +band_len[n]),
+ * weights in band_wT[n*lpad .. ] (zero padded, n_filters*lpad <= 4096); band_slot[q*64 + lane] names the
+ * filter lane handles in pass q (-1 none); slot_len_host[q] (HOST array, n_slots <= 4 ints, multiples of 4,
+ * <= lpad) is the longest band of pass q.
+ * Exact for any bank whose columns are zero outside their band (the host builds the bands from the dense
+ * bank); dense banks use at_mel_project.  out_complex_or_null == NULL: features only (MFCC).
+ * feat: (B*T, n_filters), or (B, n_filters, T) when feat_channel_major. */
+int at_stft_mel_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
+                        const float *window, const int32_t *band_start, const int32_t *band_len,
+                        const int32_t *band_slot, const float *band_wT, int n_filters, int lpad, int n_slots,
+                        const int32_t *slot_len_host, int contrast, int power2, const float *offset, const float *scale, float eps,
+                        float *out_complex_or_null, float *phase_or_null, float *feat, int feat_channel_major,
+                        void *stream);
+
 /* ---- K3/K5/K15: inverse ------------------------------------------------ */
 /* 16 x hop table of window^2 sums used by at_istft for n_fft=1024, hop=256
  * (torch.istft's window envelope; stft.py:126-127).  env16: 16*hop floats. */

@@ -192,3 +192,65 @@ def test_zero_block_skipping_keeps_dense_semantics(dev):
     assert np.array_equal(np.isinf(y), np.isinf(yr))
     ok = np.isfinite(yr)
     assert np.abs(y[ok] - yr[ok]).max() / np.abs(yr[ok]).max() < TOL
+
+
+def test_fused_stft_mel_equals_separate_stages(dev):
+    """Compose(STFT|DGT + Magnitude(banded bank)) runs as one kernel: same features as the two-stage path and
+    as the oracle, the spectrum side effects (phase buffer, keep_input) intact."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(5, 2, 9000, generator=g) * 0.1
+    for cls, w in [(A.STFT, O.hann_window(1024)), (A.DGT, O.gauss_window(1024))]:
+        for contrast, mode in [("log1p", "unipolar"), ("log", "gaussian"), (None, None)]:
+            st = cls().to(dev)
+            mg = A.Magnitude(n_mels=128, mode=mode, contrast=contrast).to(dev)
+            comp = st + mg
+            xd = x.to(dev)
+            comp.scale_data(xd)
+            assert mg.can_fuse_with(st, xd)
+            y = comp(xd)                                  # fused
+            y2 = mg(st(xd))                               # stage by stage (MFMA projection)
+            assert y.shape == y2.shape == (5, 2, 36, 128)
+            assert rel_max(cpu(y), cpu(y2)) < TOL
+            Xr = O.stft_forward(x, w, 1024, 256)
+            fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100))
+            off = sc = None
+            if mode is not None:
+                off, sc = O.magnitude_scale_stats(Xr, contrast, mode)
+            yr = O.magnitude_forward(Xr, fwd, contrast, off, sc)
+            assert rel_max(cpu(y), yr.numpy()) < TOL
+            # spectrum side effects of the STFT stage survive the fusion
+            Xn = Xr.reshape(10, 36, 513).numpy()
+            big = np.abs(Xn) > 1e-2
+            dphi = np.angle(np.exp(1j * (cpu(st.phase_buffer.reshape(10, 36, 513)) - np.angle(Xn))))
+            assert np.abs(dphi[big]).max() < 1e-3
+    # not fusable: odd clip length, reference-default 513-filter bank, realtime stage -> plain two-stage path
+    st, mg = A.STFT().to(dev), A.Magnitude(n_mels=128, mode=None).to(dev)
+    assert not mg.can_fuse_with(st, torch.zeros(2, 9001, device=dev))
+    assert not A.Magnitude(mode=None).to(dev).can_fuse_with(st, torch.zeros(2, 9000, device=dev))
+    assert not mg.can_fuse_with(A.RealtimeSTFT().to(dev), torch.zeros(2, 9000, device=dev))
+    yo = (st + mg)(x[..., :8999].to(dev))
+    assert yo.shape == (5, 2, 36, 128)
+    # editing the bank buffer invalidates the cached band table
+    mg.mel_bank[0, 100, 5] = 0.5
+    y_edit = (st + mg)(x.to(dev))
+    assert rel_max(cpu(y_edit), cpu(mg(st(x.to(dev))))) < TOL
+
+
+def test_fused_random_banded_bank(dev):
+    g = torch.Generator().manual_seed(32)
+    K, N = 513, 96
+    bank = torch.zeros(K, N)
+    for n in range(N):
+        s0 = int(torch.randint(0, K - 70, (1,), generator=g))
+        ln = int(torch.randint(1, 60, (1,), generator=g))
+        bank[s0:s0 + ln, n] = torch.rand(ln, generator=g)
+    bank[:, 7] = 0.0                                        # an empty filter
+    x = torch.randn(3, 5000, generator=g) * 0.1
+    st = A.STFT().to(dev)
+    mg = A.Magnitude(n_mels=N, mode=None, contrast="log1p")
+    mg._set_bank(bank)
+    mg = mg.to(dev)
+    y = (st + mg)(x.to(dev))
+    Xr = O.stft_forward(x, O.hann_window(1024), 1024, 256)
+    fwd, _ = O.magnitude_banks(bank)
+    assert rel_max(cpu(y), O.magnitude_forward(Xr, fwd, "log1p").numpy()) < TOL
