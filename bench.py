@@ -224,11 +224,13 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(dominant)
+            key = dominant if (fused or dominant != "stft_fwd") else "stft_fwd_unfused"
+            traffic = json.load(open(pmc)).get(key)
         except Exception:
             traffic = None
     roof["traffic"] = traffic
-    roof["kernel"] = {"stft_fwd": "stft1024_fwd_kernel", "istft": "istft1024_ola_kernel"}[dominant]
+    roof["kernel"] = {"stft_fwd": "stft1024_h256_fwd_kernel<false,%d>" % (1 if fused else 0),
+                      "istft": "istft1024_ola_kernel<0>"}[dominant]
 
     extras = {}
     if not args.no_extras:
