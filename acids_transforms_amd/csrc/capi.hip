@@ -136,7 +136,7 @@ int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_strid
   if (n_fft != 1024 || hop != 256 || (clip_stride & 1)) return AT_EUNSUPPORTED;
   if (B * T == 0) return AT_OK;
   if (!x || !window || !feat || !band_start || !band_len || !band_slot || !band_wT) return AT_EINVAL;
-  if (n_filters <= 0 || lpad <= 0 || n_slots <= 0 || n_slots > 4 || !slot_len_host) return AT_EINVAL;
+  if (n_filters <= 0 || lpad <= 0 || (lpad & 3) || n_slots <= 0 || n_slots > 4 || !slot_len_host) return AT_EINVAL;
   if ((long long)n_filters * lpad > 4096) return AT_EUNSUPPORTED;   // LDS copy of the band weights
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
   if (L <= n_fft / 2 || (((uintptr_t)window) & 7)) return AT_EINVAL;

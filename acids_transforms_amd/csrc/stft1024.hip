@@ -317,15 +317,17 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 3) void stft1024_h256_fwd_kernel(Fw
         if (q >= p.bank.n_slots) break;
         const int f = mel_f[q];
         const int fs = f >= 0 ? f : 0;
-        const float* a = absrow + mel_st[q];
-        const float* w = wlds + fs * p.bank.lpad;
+        // band starts and weight rows are 16-byte aligned: one ds_read_b128 each per four multiply-adds
+        const float4* a = reinterpret_cast<const float4*>(absrow + mel_st[q]);
+        const float4* w = reinterpret_cast<const float4*>(wlds + fs * p.bank.lpad);
         float acc = 0.f;
-        const int steps = p.bank.slot_len[q];            // wave-uniform; shorter bands multiply zeros
-        for (int j = 0; j < steps; j += 4) {
-          acc = fmaf(a[j], w[j], acc);
-          acc = fmaf(a[j + 1], w[j + 1], acc);
-          acc = fmaf(a[j + 2], w[j + 2], acc);
-          acc = fmaf(a[j + 3], w[j + 3], acc);
+        const int quads = p.bank.slot_len[q] >> 2;       // wave-uniform; shorter bands multiply zeros
+        for (int j = 0; j < quads; ++j) {
+          const float4 av = a[j], wv = w[j];
+          acc = fmaf(av.x, wv.x, acc);
+          acc = fmaf(av.y, wv.y, acc);
+          acc = fmaf(av.z, wv.z, acc);
+          acc = fmaf(av.w, wv.w, acc);
         }
         if (f >= 0) {
           acc = fwd_contrast(acc, p.contrast, p.eps);

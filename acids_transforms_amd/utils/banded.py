@@ -23,12 +23,16 @@ class BandedBank:
         has = nz.any(0)
         first = np.where(has, nz.argmax(0), 0)
         last = np.where(has, K - 1 - nz[::-1].argmax(0), -1)
-        length = (last - first + 1).astype(np.int32)
+        first = (first // 4) * 4                     # bands start on a 16-byte boundary: ds_read_b128 walks
+        length = np.where(has, last - first + 1, 0).astype(np.int32)
         self.lmax = int(length.max()) if N else 0
         self.n_slots = (N + 63) // 64
-        # row length of the weight table: the longest band rounded up to the 4-way unrolled walk, plus one so
-        # that it is odd -- lane l reads w[l' * lpad + j], and an odd stride spreads 32 lanes over 32 LDS banks
-        lpad = max(4, (self.lmax + 3) // 4 * 4) + 1
+        # row length of the weight table: the longest band rounded up to whole 16-byte quads, and an odd number
+        # of quads -- lane l reads quad (l' * lpad/4 + j/4), an odd quad stride spreads 16 lanes over the
+        # 16 quad slots of the 256-byte LDS bank row (conflict-free ds_read_b128)
+        lpad = max(4, (self.lmax + 3) // 4 * 4)
+        if (lpad // 4) % 2 == 0 and N * (lpad + 4) <= 4096:
+            lpad += 4
         self.eligible = bool(0 < N and self.n_slots <= MAX_SLOTS and self.lmax <= MAX_BAND and N * lpad <= 4096)
         if not self.eligible:
             return

@@ -57,7 +57,8 @@ int at_stft_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, i
 /* Fused forward for Compose(STFT|DGT -> Magnitude(mel)) and for MFCC (n_fft = 1024, hop = 256):
  * the same framing + rFFT kernel additionally emits normalise(contrast(|X|^p @ bank)) from registers, so
  * the spectrum is not re-read (spectral_repr.py:215-226 / mel.py:43-44,68-73 behind stft.py:98-104).
- * The bank is passed in banded form: filter n has its non-zero rows in [band_start[n], +band_len[n]),
+ * The bank is passed in banded form: filter n has its non-zero rows in [band_start[n], +band_len[n])
+ * (band_start a multiple of 4, lpad a multiple of 4),
  * weights in band_wT[n*lpad .. ] (zero padded, n_filters*lpad <= 4096); band_slot[q*64 + lane] names the
  * filter lane handles in pass q (-1 none); slot_len_host[q] (HOST array, n_slots <= 4 ints, multiples of 4,
  * <= lpad) is the longest band of pass q.
