@@ -142,6 +142,8 @@ struct HgiParams {
   int T, F;
   float abstol, tol;
   long long* npops;     // optional (B) number of pops per clip
+  int heap_lds_cap;     // heap entries kept in LDS per clip (2^k - 1)
+  int prof;             // dev only (ACIDS_PGHI_PROF=1): cycle counters go to `order` instead of the pop order
   int* order;           // optional (B, T*F) pop order (row*F+col), for the parity tests
 };
 
@@ -281,12 +283,29 @@ __device__ __forceinline__ u64 pack_item(float key, int idx) {
 __device__ __forceinline__ float item_key(u64 e) { return __uint_as_float((unsigned)(e >> 32)); }
 __device__ __forceinline__ int item_idx(u64 e) { return (int)(unsigned)e; }
 
-__device__ __forceinline__ u64 hload(const u64* p) {
+__device__ __forceinline__ u64 gload(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void hstore(u64* p, u64 v) {
+__device__ __forceinline__ void gstore(u64* p, u64 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// The heap array: positions [0, cap) live in this wave's LDS (the top levels, where every pop starts),
+// the rest in the clip's global workspace.  Same array, same indices -- only the storage differs.
+// cap = 2^k - 1 is chosen at launch from the batch size: 4095 entries (32 KB) while <= 4 clips share a
+// CU, fewer when more clips have to be resident at once.
+struct Heap {
+  u64* top;   // LDS, cap entries
+  u64* rest;  // global, indexed by absolute position
+  int cap;
+  __device__ __forceinline__ u64 load(long long pos) const {
+    return pos < cap ? top[pos] : gload(rest + pos);
+  }
+  __device__ __forceinline__ void store(long long pos, u64 v) const {
+    if (pos < cap) top[pos] = v;
+    else gstore(rest + pos, v);
+  }
+};
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
   const unsigned lo = __shfl((unsigned)v, src, 64);
   const unsigned hi = __shfl((unsigned)(v >> 32), src, 64);
@@ -298,19 +317,19 @@ __device__ __forceinline__ float fload(const float* p) {   // L2-served load of 
 }
 
 // place `item` at `pos` and let it rise (utils/heapq.py:9-21 with startpos = 0)
-__device__ __forceinline__ void coop_siftdown(u64* H, int pos, u64 item, int lane) {
+__device__ __forceinline__ void coop_siftdown(const Heap& H, int pos, u64 item, int lane) {
   const unsigned q = (unsigned)pos + 1u;
   const int depth = 31 - __clz(q);                // number of ancestors (< 31)
   const int sh = lane < 31 ? lane : 30;           // lanes >= depth are idle; keep their shifts defined
   const int my_dst = (int)(q >> sh) - 1;          // lane L: position of ancestor L-1 (L = 0: pos itself)
   const int my_anc = (int)(q >> (sh + 1)) - 1;    // lane L: position of ancestor L
   u64 anc = 0;
-  if (lane < depth) anc = hload(H + my_anc);
+  if (lane < depth) anc = H.load(my_anc);
   const bool rises = (lane < depth) && (item_key(item) < item_key(anc));
   const u64 mask = __ballot(rises);
   const int m = (mask == ~0ull) ? 64 : __builtin_ctzll(~mask);  // item passes ancestors 0 .. m-1
-  if (lane < m) hstore(H + my_dst, anc);
-  else if (lane == m) hstore(H + my_dst, item);
+  if (lane < m) H.store(my_dst, anc);
+  else if (lane == m) H.store(my_dst, item);
 }
 
 // sibling's value through DPP (lane ^ 1): pure VALU, no LDS crossbar
@@ -327,7 +346,7 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
 
 // utils/heapq.py:51-59 (+ :24-42): the bubble-up part of heappop after `last` was taken off the end
 // (n = remaining size >= 1).  Returns the leaf position where `last` has to be placed.
-__device__ __forceinline__ int coop_bubble(u64* H, int n, int lane) {
+__device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64& leaf_old) {
   int pos = 0;  // the hole
   const int lvl = 31 - __clz((unsigned)lane | 1u);
   const int off = lane - (1 << lvl);
@@ -336,7 +355,7 @@ __device__ __forceinline__ int coop_bubble(u64* H, int n, int lane) {
     // subtree under the hole: local node `lane` (1..63) <-> global index g
     const long long g = (((long long)pos + 1) << lvl) - 1 + off;
     const bool valid = (lane >= 1) && (g < (long long)n);
-    const u64 val = valid ? hload(H + g) : kInf;
+    const u64 val = valid ? H.load(g) : kInf;
     const float key = item_key(val);
     // "am I the child my parent bubbles up?"  children 2i (left, even lane) and 2i+1 (right, odd lane) are
     // DPP neighbours.  heapq.py:33: take the right child iff it exists and not (left < right).
@@ -364,10 +383,13 @@ __device__ __forceinline__ int coop_bubble(u64* H, int n, int lane) {
     const int cl = (2 * lane) & 63;
     const int nx = ((W >> cl) & 1ull) ? cl : cl + 1;
     const u64 moved = shfl64(val, nx);
-    if ((pathmask >> lane) & 1ull) hstore(H + g, moved);
+    if ((pathmask >> lane) & 1ull) H.store(g, moved);
     const int gcur = __builtin_amdgcn_readlane((int)g, cur);
     pos = gcur;
-    if (steps < 5 || 2LL * gcur + 1 >= (long long)n) break;
+    if (steps < 5 || 2LL * gcur + 1 >= (long long)n) {
+      leaf_old = readlane64(val, cur);   // what the final hole held: now the value of its parent
+      break;
+    }
   }
   return pos;
 }
@@ -382,7 +404,8 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
   const float* tg = p.tgradw + b * n;
   const float* fg = p.fgradw + b * n;
   float* phase = p.phase + b * n;
-  u64* H = reinterpret_cast<u64*>(p.heap + b * (n + 2));
+  extern __shared__ __attribute__((aligned(16))) u64 heap_top[];
+  const Heap H = {heap_top, reinterpret_cast<u64*>(p.heap + b * (n + 2)), p.heap_lds_cap};
   int* order = p.order ? p.order + b * n : nullptr;
   const float abstol = p.abstol;
 
@@ -393,8 +416,10 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
   clip_argmax(spec, n, abstol, 0.f, false, lane, max_val, max_pos);  // :173-174
   const float thr = max_val * p.tol;                                   // :177-178
   long long npops = 0;
+  long long c_pop1 = 0, c_bubble = 0, c_sift = 0, c_nb = 0, c_push = 0, n_push = 0;
+#define TICK() ((long long)__builtin_amdgcn_s_memtime())
   if (lane == 0) {
-    hstore(H, pack_item(-max_val, (int)max_pos));  // :175
+    H.store(0, pack_item(-max_val, (int)max_pos));  // :175
     spec[max_pos] = abstol;                         // :176
   }
   int hn = 1;
@@ -403,12 +428,14 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
   while (max_val > abstol) {  // :179
     while (hn > 0) {          // :180
       hn = uni(hn);
+      const long long t0 = p.prof ? TICK() : 0;
       // heappop, part 1: take the last entry off, read the root (heapq.py:51-56)
-      const u64 last = hload(H + (hn - 1));
+      const u64 last = H.load(hn - 1);     // usually deep in the global part: not needed before the leaf is known
       hn -= 1;
-      const u64 it = (hn == 0) ? last : hload(H);
-      const int c = uni(item_idx(it));
-      if (order && lane == 0) order[npops] = c;
+      int c;
+      if (hn == 0) c = uni(item_idx(last));
+      else c = uni(item_idx(H.load(0)));
+      if (order && !p.prof && lane == 0) order[npops] = c;
       ++npops;
       const int col = c / F;        // frame
       const int row = c - col * F;  // bin
@@ -426,11 +453,23 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
         g_n = gr[nb];
         pc = fload(phase + c);
       }
+      const long long t1 = p.prof ? TICK() : 0;
       // heappop, part 2: bubble the smaller children up, drop `last` into the leaf, let it rise
+      long long t2 = t1;
       if (hn > 0) {
-        const int leaf = coop_bubble(H, hn, lane);
-        coop_siftdown(H, leaf, last, lane);
+        u64 leaf_old = 0;
+        const int leaf = coop_bubble(H, hn, lane, leaf_old);
+        t2 = p.prof ? TICK() : 0;
+        // `last` goes into the leaf and rises while it is smaller than its parent (heapq.py:39-42).  The
+        // parent of the leaf now holds the entry that just left the leaf, which is still in registers: in
+        // the common case (`last` does not rise at all) no ancestor has to be read back.
+        if (leaf == 0 || !(item_key(last) < item_key(leaf_old))) {
+          if (lane == 0) H.store(leaf, last);
+        } else {
+          coop_siftdown(H, leaf, last, lane);
+        }
       }
+      const long long t3 = p.prof ? TICK() : 0;
       const bool lv = (lane < 4) && inb && live(s, abstol, thr);
       if (lv) {
         const int nb = c + d;
@@ -439,6 +478,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
         spec[nb] = abstol;
       }
       const u64 lvmask = __ballot(lv);
+      const long long t4 = p.prof ? TICK() : 0;
       const u64 mine = pack_item(-s, c + d);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -446,7 +486,12 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
           const u64 item = readlane64(mine, q);
           coop_siftdown(H, hn, item, lane);  // heappush (heapq.py:45-48)
           ++hn;
+          ++n_push;
         }
+      }
+      if (p.prof) {
+        const long long t5 = TICK();
+        c_pop1 += t1 - t0; c_bubble += t2 - t1; c_sift += t3 - t2; c_nb += t4 - t3; c_push += t5 - t4;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -454,13 +499,18 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
     // :216-219 reseed from the global max of what is left (lane-parallel scan)
     clip_argmax(spec, n, abstol, thr, true, lane, max_val, max_pos);
     if (lane == 0) {
-      hstore(H, pack_item(-max_val, (int)max_pos));
+      H.store(0, pack_item(-max_val, (int)max_pos));
       spec[max_pos] = abstol;
     }
     hn = 1;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
   if (p.npops && lane == 0) p.npops[b] = npops;
+  if (p.prof && order && lane == 0 && b == 0) {
+    long long* o = reinterpret_cast<long long*>(order);
+    o[0] = npops; o[1] = c_pop1; o[2] = c_bubble; o[3] = c_sift; o[4] = c_nb; o[5] = c_push; o[6] = n_push;
+  }
+#undef TICK
 }
 
 // ---------------------------------------------------------------------------
@@ -821,13 +871,25 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
   hipStream_t s = (hipStream_t)stream;
   GradParams g = {mag, spec, tg, fg, (long long)B, T, F, n_fft, hop, gamma, abstol};
   hipLaunchKernelGGL(pghi_grad_offline_kernel, dim3(grid1d((long long)B * T * F)), dim3(256), 0, s, g);
-  HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, order_or_null};
+  static const int prof = [] { const char* e = getenv("ACIDS_PGHI_PROF"); return (e && e[0] == '1') ? 1 : 0; }();
+  // LDS share of the heap: as much as fits while every clip of the batch can still be resident (160 KB per CU)
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  const long long per_cu = (B + cus - 1) / cus;
+  const int cap = per_cu <= 4 ? 4095 : per_cu <= 8 ? 2047 : per_cu <= 16 ? 1023 : 511;
+  HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, cap, prof, order_or_null};
   // ACIDS_PGHI_SERIAL=1 selects the single-lane reference kernel (debugging aid; identical results)
   static const bool serial = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
   if (serial)
     hipLaunchKernelGGL(pghi_hgi_offline_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
   else
-    hipLaunchKernelGGL(pghi_hgi_offline_coop_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
+    hipLaunchKernelGGL(pghi_hgi_offline_coop_kernel, dim3((unsigned)B), dim3(64), sizeof(u64) * (size_t)(cap + 1), s, h);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 

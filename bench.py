@@ -233,74 +233,92 @@ def main():
                       "istft": "istft1024_ola_kernel<0>"}[dominant]
 
     extras = {}
-    if not args.no_extras:
-        # (a) features reassembled on every rank with one RCCL all-gather, overlapped with the next step's compute
-        if world > 1 and not rehearsal:
-            from acids_transforms_amd.dist import all_gather_features
-            comm = torch.cuda.Stream(device=dev)
-            torch.cuda.synchronize()
-            barrier()
-            t1 = time.perf_counter()
-            pending = None
-            for _ in range(args.steps):
-                _, feat, _, _ = step()
-                done = torch.cuda.Event()
-                done.record()
-                if pending is not None:
-                    pending.wait()
-                with torch.cuda.stream(comm):
-                    comm.wait_event(done)
-                    feat.record_stream(comm)
-                    _, pending = all_gather_features(feat, world * B, async_op=True)
+
+    def guarded(name, fn):
+        """Side measurements must never cost the headline line."""
+        try:
+            out = fn()
+            if out is not None:
+                extras[name] = out
+        except Exception as exc:
+            extras[name + "_error"] = repr(exc)[:300]
+
+    def extra_allgather():
+        # features reassembled on every rank with one RCCL all-gather on a side stream, overlapped with the next step
+        from acids_transforms_amd.dist import all_gather_features
+        comm = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        pending = None
+        for _ in range(args.steps):
+            _, feat, _, _ = step()
+            done = torch.cuda.Event()
+            done.record()
             if pending is not None:
                 pending.wait()
+            with torch.cuda.stream(comm):
+                comm.wait_event(done)
+                feat.record_stream(comm)
+                _, pending = all_gather_features(feat, world * B, async_op=True)
+        if pending is not None:
+            pending.wait()
+        torch.cuda.synchronize()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return world * frames_per_step * args.steps / float(tt.item())
+
+    def extra_pghi():
+        # BASELINE config 3: DGT + PGHI invert round trip, dense noise (worst case: every bin above tolerance).
+        # One wave per clip, latency-bound: throughput grows with the number of clips in flight.
+        dgt = A.DGT(sr=SR, n_fft=N_FFT, hop_length=HOP).to(dev)
+        pg = {}
+        for nb in sorted({min(args.pghi_clips, B), min(4 * args.pghi_clips, 4096)}):
+            xs = x if nb <= B else torch.randn(nb, CLIP_LEN, device=dev, generator=gen) * 0.1
+            m = dgt(xs[:nb]).abs()
             torch.cuda.synchronize()
-            barrier()
+            t1 = time.perf_counter()
+            yp = dgt.invert(m, inversion_mode="pghi")
+            torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            extras["with_feature_allgather_frames_per_s"] = world * frames_per_step * args.steps / float(tt.item())
-        # (b) BASELINE config 3: DGT + PGHI invert round trip, dense noise (worst case: every bin above
-        #     tolerance).  One wave per clip, latency-bound: throughput grows with the number of clips in flight.
+            pg["clips_%d" % nb] = {"frames_per_s": nb * T_FRAMES / dt, "seconds": dt,
+                                   "heap_pops_per_s": float(nb) * T_FRAMES * F_BINS / dt}
+            del m, yp, xs
+        pg["input"] = "|DGT(randn*0.1)|: ~100% of bins above tolerance; PGHI + polar ISTFT"
+        return pg
+
+    def extra_stream():
+        # BASELINE config 5 (streaming): chunk -> OverlapAdd frames -> RealtimeDGT -> |X| -> RTPGHI -> irfft ->
+        # overlap-add, 1024-sample chunks (4 hops; the reference's streaming state needs chunks >= 768 samples),
+        # eager launches vs one hipGraph replay per chunk
+        from acids_transforms_amd.streaming import StreamingDGTSession
+        S, C = args.streams, 1024
+        chunk = torch.randn(S, C, device=dev, generator=gen) * 0.1
+        rtres = {"streams": S, "chunk_samples": C, "realtime_budget_ms": C / SR * 1e3}
+        for tag, use_graph in (("eager", False), ("hipgraph", True)):
+            sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=use_graph)
+            for _ in range(3):
+                sess.step(chunk)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nst = 50
+            for _ in range(nst):
+                sess.step(chunk)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / nst
+            rtres["ms_per_chunk_" + tag] = dt * 1e3
+            rtres["frames_per_s_" + tag] = S * (C // HOP) / dt
+            del sess
+        return rtres
+
+    if not args.no_extras:
+        if world > 1 and not rehearsal:
+            guarded("with_feature_allgather_frames_per_s", extra_allgather)
         if rank == 0 and args.pghi_clips > 0:
-            dgt = A.DGT(sr=SR, n_fft=N_FFT, hop_length=HOP).to(dev)
-            pg = {}
-            for nb in sorted({min(args.pghi_clips, B), min(4 * args.pghi_clips, 4096)}):
-                xs = x if nb <= B else torch.randn(nb, CLIP_LEN, device=dev, generator=gen) * 0.1
-                m = dgt(xs[:nb]).abs()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                yp = dgt.invert(m, inversion_mode="pghi")
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
-                pg["clips_%d" % nb] = {"frames_per_s": nb * T_FRAMES / dt, "seconds": dt,
-                                       "heap_pops_per_s": float(nb) * T_FRAMES * F_BINS / dt}
-                del m, yp, xs
-            pg["input"] = "|DGT(randn*0.1)|: ~100% of bins above tolerance; PGHI + polar ISTFT"
-            extras["pghi_invert"] = pg
-        # (c) BASELINE config 5 (streaming): chunk -> OverlapAdd frames -> RealtimeDGT -> |X| -> RTPGHI -> irfft ->
-        #     overlap-add, 1024-sample chunks (4 hops; the reference's streaming state needs chunks >= 768 samples),
-        #     eager launches vs one hipGraph replay per chunk
+            guarded("pghi_invert", extra_pghi)
         if rank == 0 and args.streams > 0:
-            from acids_transforms_amd.streaming import StreamingDGTSession
-            S, C = args.streams, 1024
-            chunk = torch.randn(S, C, device=dev, generator=gen) * 0.1
-            rtres = {"streams": S, "chunk_samples": C, "realtime_budget_ms": C / SR * 1e3}
-            for tag, use_graph in (("eager", False), ("hipgraph", True)):
-                sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=use_graph)
-                for _ in range(3):
-                    sess.step(chunk)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                nst = 50
-                for _ in range(nst):
-                    sess.step(chunk)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / nst
-                rtres["ms_per_chunk_" + tag] = dt * 1e3
-                rtres["frames_per_s_" + tag] = S * (C // HOP) / dt
-                del sess
-            extras["realtime_dgt_stream"] = rtres
+            guarded("realtime_dgt_stream", extra_stream)
         barrier()
 
     result = {
