@@ -277,6 +277,8 @@ def main():
         for nb in sorted({min(args.pghi_clips, B), min(4 * args.pghi_clips, 4096)}):
             xs = x if nb <= B else torch.randn(nb, CLIP_LEN, device=dev, generator=gen) * 0.1
             m = dgt(xs[:nb]).abs()
+            yp = dgt.invert(m, inversion_mode="pghi")      # warm-up: first-touch of the (7 MB/clip) workspace
+            del yp
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             yp = dgt.invert(m, inversion_mode="pghi")
