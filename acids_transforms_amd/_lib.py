@@ -24,7 +24,7 @@ _SIGNATURES = {
     "at_error_string": [c_int],
     "at_init": [c_int],
     "at_stft_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
-    "at_stft_mel_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int,
+    "at_stft_mel_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_int,
                             c_f, c_int, c_int, c_f, c_f, c_flt, c_f, c_f, c_f, c_int, c_f],
     "at_istft_envelope_table": [c_f, c_int, c_int, c_f, c_f],
     "at_istft_workspace_bytes": [c_i64, c_i64, c_int, c_int],

@@ -12,12 +12,11 @@ namespace at_hip {
 int launch_stft1024_fwd(const float*, long long, long long, long long, long long, int, int, const float*,
                         const float2*, float2*, float*, hipStream_t);
 struct BandBank {
-  const int* start;
-  const int* len;
-  const int* slot;
-  const float* wT;
-  int n_filters, lpad, n_slots;
-  int slot_len[4];
+  const int* lane_filter;
+  const int* lane_start;
+  const float* weights;
+  int n_filters, n_passes;
+  int pass_len[4];
 };
 int launch_stft1024_h256_fwd(const float*, long long, long long, long long, long long, const float*, const float2*,
                              float2*, float*, const BandBank*, float*, const float*, const float*, float, int, int, int,
@@ -127,26 +126,28 @@ int at_stft_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, i
 }
 
 int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
-                        const float* window, const int32_t* band_start, const int32_t* band_len,
-                        const int32_t* band_slot, const float* band_wT, int n_filters, int lpad, int n_slots,
-                        const int32_t* slot_len_host, int contrast, int power2, const float* offset, const float* scale, float eps,
+                        const float* window, const int32_t* lane_filter, const int32_t* lane_start,
+                        const float* band_weights, int n_filters, int n_passes, const int32_t* pass_len_host,
+                        int contrast, int power2, const float* offset, const float* scale, float eps,
                         float* out_complex_or_null, float* phase_or_null, float* feat, int feat_channel_major,
                         void* stream) {
   if (B < 0 || T < 0 || L < 0) return AT_EINVAL;
   if (n_fft != 1024 || hop != 256 || (clip_stride & 1)) return AT_EUNSUPPORTED;
   if (B * T == 0) return AT_OK;
-  if (!x || !window || !feat || !band_start || !band_len || !band_slot || !band_wT) return AT_EINVAL;
-  if (n_filters <= 0 || lpad <= 0 || (lpad & 3) || n_slots <= 0 || n_slots > 4 || !slot_len_host) return AT_EINVAL;
-  if ((long long)n_filters * lpad > 4096) return AT_EUNSUPPORTED;   // LDS copy of the band weights
+  if (!x || !window || !feat || !lane_filter || !lane_start || !band_weights || !pass_len_host) return AT_EINVAL;
+  if (n_filters <= 0 || n_passes <= 0 || n_passes > 4 || n_filters > 64 * n_passes) return AT_EINVAL;
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
-  if (L <= n_fft / 2 || (((uintptr_t)window) & 7)) return AT_EINVAL;
+  if (L <= n_fft / 2 || (((uintptr_t)window) & 7) || (((uintptr_t)band_weights) & 15)) return AT_EINVAL;
   const float2* tw = twiddles_for_current_device();
   if (!tw) return AT_ENOTINIT;
-  BandBank bank = {band_start, band_len, band_slot, band_wT, n_filters, lpad, n_slots, {0, 0, 0, 0}};
-  for (int q = 0; q < n_slots; ++q) {
-    if (slot_len_host[q] < 0 || slot_len_host[q] > lpad || (slot_len_host[q] & 3)) return AT_EINVAL;  // 4-way unrolled walk
-    bank.slot_len[q] = slot_len_host[q];
+  BandBank bank = {lane_filter, lane_start, band_weights, n_filters, n_passes, {0, 0, 0, 0}};
+  long long table_floats = 0;
+  for (int q = 0; q < n_passes; ++q) {
+    if (pass_len_host[q] < 0 || pass_len_host[q] > 128 || (pass_len_host[q] & 3)) return AT_EINVAL;  // 4 bins per step
+    bank.pass_len[q] = pass_len_host[q];
+    table_floats += 64LL * pass_len_host[q];
   }
+  if (table_floats > 8192) return AT_EUNSUPPORTED;   // LDS copy of the band weights
   return launch_stft1024_h256_fwd(x, B, L, clip_stride, T, window, tw, (float2*)out_complex_or_null, phase_or_null, &bank,
                                   feat, offset, scale, eps, contrast, power2, feat_channel_major, (hipStream_t)stream);
 }

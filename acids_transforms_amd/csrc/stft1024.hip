@@ -140,18 +140,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stft1024_fwd_kernel(FwdP
 // shifted by two slots per frame, and only the 256 new samples (two 8-byte loads
 // per lane) are fetched per frame -- 1 KB of loads per frame instead of 4 KB.
 // ---------------------------------------------------------------------------
-// Banded filterbank for the fused |X| -> mel epilogue: filter n has its non-zero weights in
-// rows [start[n], start[n]+len[n]) of the (F x N) bank, stored row-major in wT[n][0..lpad).
-// slot[q*64 + lane] = filter handled by `lane` in pass q (-1 = none); long and short filters are paired.
+// Banded filterbank for the fused |X| -> mel epilogue (host side: utils/banded.py).  In pass q lane l sums
+// filter lane_filter[q*64+l] (-1: none) over pass_len[q] bins starting at bin lane_start[q*64+l] (a multiple
+// of 4), four bins per step.  The weights are stored pass-major, step-major, lane-minor -- the float4 of
+// step j sits at float4 index (quad_base[q] + j) * 64 + l -- so a wave's weight read is 1 KB contiguous
+// (conflict-free ds_read_b128); the host picks the lanes so that the magnitude reads do not collide either.
 struct BandBank {
-  const int* start;
-  const int* len;
-  const int* slot;
-  const float* wT;
-  int n_filters, lpad, n_slots;
-  int slot_len[4];   // longest band in each pass, rounded up to a multiple of 4 (<= lpad)
+  const int* lane_filter;
+  const int* lane_start;
+  const float* weights;
+  int n_filters, n_passes;
+  int pass_len[4];   // bins walked in each pass (multiple of 4)
 };
-constexpr int kMaxBandFloats = 4096;   // LDS copy of the band weights (n_filters * lpad floats, 16 KB)
+constexpr int kMaxBandFloats = 8192;   // LDS copy of the weights (dynamic LDS): 64 * sum(pass_len) floats <= 32 KB
 
 struct FwdRunParams {
   const float* x;
@@ -183,7 +184,6 @@ __device__ __forceinline__ float2 load_pair(const float* clip, long long L, long
   return make_float2(clip[reflect_index(i0 + lane_off, L)], clip[reflect_index(i0 + lane_off + 1, L)]);
 }
 
-constexpr int FWD_WAVES = 4;  // 5 x 4.5 KB slabs + 15 KB tables = 37.7 KB -> 4 blocks = 20 waves per CU
 
 __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
   switch (mode) {
@@ -194,21 +194,37 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
   }
 }
 
-// MEL: 0 = spectrum only; 1 = spectrum + fused banded-filterbank features; 2 = features only
-template <bool WRITE_PHASE, int MEL>
-__global__ __launch_bounds__(64 * FWD_WAVES, 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
-  __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTwiddleCount + 512 + (MEL ? kMaxBandFloats / 2 : 0)];
+// MEL: 0 = spectrum only; 1 = spectrum + fused banded-filterbank features; 2 = features only.
+// FWD_WAVES waves per workgroup share the LDS constant tables (twiddles are always staged there; TWLDS makes
+// the FFT read them at the point of use instead of holding 44 VGPRs, which buys a fourth wave per SIMD).
+template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS>
+__global__ __launch_bounds__(64 * FWD_WAVES, TWLDS ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
+  constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
+  __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
+  extern __shared__ float4 band_lds[];   // MEL != 0: the bank's weight table, sized by the launcher
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + FWD_WAVES * kFftLdsFloat2PerWave;
-  // workgroup-shared constants: twiddle table and analysis window
-  for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * FWD_WAVES) tab[i] = p.tw[i];
+  // workgroup-shared constants: (twiddle table,) analysis window, band weights
+  if (TWLDS)
+    for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * FWD_WAVES) tab[i] = p.tw[i];
   for (int i = threadIdx.x; i < 512; i += 64 * FWD_WAVES)
-    tab[kTwiddleCount + i] = reinterpret_cast<const float2*>(p.window)[i];
-  float* wlds = reinterpret_cast<float*>(tab + kTwiddleCount + 512);   // band weights, workgroup-shared
-  if (MEL != 0)
-    for (int i = threadIdx.x; i < p.bank.n_filters * p.bank.lpad; i += 64 * FWD_WAVES) wlds[i] = p.bank.wT[i];
+    tab[kTabTw + i] = reinterpret_cast<const float2*>(p.window)[i];
+  float* wlds = reinterpret_cast<float*>(band_lds);
+  int* lane_tab = nullptr;
+  if (MEL != 0) {
+    int table_floats = 0;
+    for (int q = 0; q < p.bank.n_passes; ++q) table_floats += 64 * p.bank.pass_len[q];
+    for (int i = threadIdx.x; i < table_floats; i += 64 * FWD_WAVES) wlds[i] = p.bank.weights[i];
+    // per-lane walk descriptors behind the weights: re-read each frame (two ds_read_b32 per pass) rather
+    // than held in eight VGPRs -- the frame loop is at the 168-register limit of three waves per SIMD
+    lane_tab = reinterpret_cast<int*>(wlds + table_floats);
+    for (int i = threadIdx.x; i < 64 * p.bank.n_passes; i += 64 * FWD_WAVES) {
+      lane_tab[i] = p.bank.lane_start[i];
+      lane_tab[64 * p.bank.n_passes + i] = p.bank.lane_filter[i];
+    }
+  }
   __syncthreads();
 
   const long long run = (long long)blockIdx.x * FWD_WAVES + wave;
@@ -220,9 +236,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 3) void stft1024_h256_fwd_kernel(Fw
   if (t1 > p.T) t1 = p.T;
   if (t0 >= t1) return;
 
-  Twiddles tw;
-  load_twiddles<false>(tw, p.tw, lane);
-  const float2* win = tab + kTwiddleCount;   // win[lane + 64 m]
+  Twiddles tw_regs;
+  if (!TWLDS) load_twiddles<false>(tw_regs, p.tw, lane);
+  const LdsTwiddles<false> tw_lds = {tab, lane};
+  const float2* win = tab + kTabTw;   // win[lane + 64 m]
 
   const float* clip = p.x + b * p.clip_stride;
   const bool clip_aligned = ((((uintptr_t)clip) & 7) == 0);  // frame starts are multiples of 256 samples
@@ -253,16 +270,6 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 3) void stft1024_h256_fwd_kernel(Fw
     mel_off = *p.offset;
     mel_sc = *p.scale;
   }
-  // this lane's filters (one per pass): index, first bank row, LDS offset of its weights -- loop invariant
-  int mel_f[4] = {-1, -1, -1, -1}, mel_st[4] = {0, 0, 0, 0};
-  if (MEL != 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < p.bank.n_slots) {
-        mel_f[q] = p.bank.slot[q * 64 + lane];
-        mel_st[q] = p.bank.start[mel_f[q] >= 0 ? mel_f[q] : 0];
-      }
-  }
 
   // one frame: window, FFT, merge, store; `n6`/`n7` are the next frame's two new segments, already requested.
   // The Nyquist bin (a one-lane, exec-masked store the compiler cannot count on) is deferred to the top of the
@@ -286,9 +293,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 3) void stft1024_h256_fwd_kernel(Fw
     for (int m = 0; m < 6; ++m) raw[m] = raw[m + 2];
     raw[6] = n6;
     raw[7] = n7;
-    fft512<false>(v, tw, lds, lane);
     float2 nyq;
-    rfft_merge(v, tw, lane, nyq);
+    if (TWLDS) {
+      fft512<false>(v, tw_lds, lds, lane);
+      rfft_merge(v, tw_lds, lane, nyq);
+    } else {
+      fft512<false>(v, tw_regs, lds, lane);
+      rfft_merge(v, tw_regs, lane, nyq);
+    }
     if (MEL != 2) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) row[lane + 64 * m] = v[m];
@@ -308,27 +320,27 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 3) void stft1024_h256_fwd_kernel(Fw
         const float s2 = fmaf(v[m].x, v[m].x, v[m].y * v[m].y);
         absrow[lane + 64 * m] = p.power2 ? s2 : __builtin_amdgcn_sqrtf(s2);
       }
-      // bin 512, then zeros: a band walk may run up to lpad - 1 entries past its filter (zero weights there)
+      // bin 512, then zeros: a walk may run past its band (zero weights there), up to entry 639
       absrow[512 + lane] = (lane == 0) ? (p.power2 ? nyq.x * nyq.x : fabsf(nyq.x)) : 0.0f;
       absrow[576 + lane] = 0.0f;
       wave_lds_sync();
+      const float4* w = reinterpret_cast<const float4*>(wlds) + lane;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (q >= p.bank.n_slots) break;
-        const int f = mel_f[q];
-        const int fs = f >= 0 ? f : 0;
-        // band starts and weight rows are 16-byte aligned: one ds_read_b128 each per four multiply-adds
-        const float4* a = reinterpret_cast<const float4*>(absrow + mel_st[q]);
-        const float4* w = reinterpret_cast<const float4*>(wlds + fs * p.bank.lpad);
+        if (q >= p.bank.n_passes) break;
+        const int f = lane_tab[(p.bank.n_passes + q) * 64 + lane];
+        // one ds_read_b128 of magnitudes and one of weights per four multiply-adds
+        const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
         float acc = 0.f;
-        const int quads = p.bank.slot_len[q] >> 2;       // wave-uniform; shorter bands multiply zeros
+        const int quads = p.bank.pass_len[q] >> 2;       // wave-uniform; shorter bands multiply zeros
         for (int j = 0; j < quads; ++j) {
-          const float4 av = a[j], wv = w[j];
+          const float4 av = a[j], wv = w[j * 64];
           acc = fmaf(av.x, wv.x, acc);
           acc = fmaf(av.y, wv.y, acc);
           acc = fmaf(av.z, wv.z, acc);
           acc = fmaf(av.w, wv.w, acc);
         }
+        w += quads * 64;
         if (f >= 0) {
           acc = fwd_contrast(acc, p.contrast, p.eps);
           if (p.offset) acc = (acc - mel_off) / mel_sc;
@@ -405,27 +417,64 @@ __device__ __forceinline__ void sincos_big(float phase, float& s, float& c) {
   c = __builtin_amdgcn_cosf(r);
 }
 
+// One frame's spectrum as it sits in HBM, loaded ahead of use and converted when consumed:
+//   IN_COMPLEX: d[m] = X[lane + 64 m],             ny0 = Re X[512]
+//   IN_POLAR:   d[m] = (mag, phase)[lane + 64 m],  (ny0, ny1) = (mag, phase)[512]
+// (the polar form keeps mag and phase in separate registers: each is the target of its own dword load)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int IN_MODE>
+struct RawFrame;
+template <>
+struct RawFrame<IN_COMPLEX> {
+  f32x2 d[8];
+  float ny0;
+};
+template <>
+struct RawFrame<IN_POLAR> {
+  float a[8], ph[8];
+  float ny0, ny1;
+};
+
+__device__ __forceinline__ void load_raw(const InvParams& p, long long f, int lane, RawFrame<IN_COMPLEX>& q) {
+  const f32x2* row = reinterpret_cast<const f32x2*>(p.X + f * F);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) q.d[m] = row[lane + 64 * m];
+  q.ny0 = row[512].x;  // broadcast load; only lane 0 uses it
+}
+__device__ __forceinline__ void load_raw(const InvParams& p, long long f, int lane, RawFrame<IN_POLAR>& q) {
+  const float* mrow = p.mag + f * F;
+  const float* prow = p.phase + f * F;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    q.a[m] = mrow[lane + 64 * m];
+    q.ph[m] = prow[lane + 64 * m];
+  }
+  q.ny0 = mrow[512];
+  q.ny1 = prow[512];
+}
+
+__device__ __forceinline__ void raw_to_spectrum(const RawFrame<IN_COMPLEX>& q, float2 (&v)[8], float& nyq_re) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = make_float2(q.d[m].x, q.d[m].y);
+  nyq_re = q.ny0;
+}
+__device__ __forceinline__ void raw_to_spectrum(const RawFrame<IN_POLAR>& q, float2 (&v)[8], float& nyq_re) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    float sn, cs;
+    sincos_big(q.ph[m], sn, cs);
+    v[m] = make_float2(q.a[m] * cs, q.a[m] * sn);
+  }
+  float sn, cs;
+  sincos_big(q.ny1, sn, cs);
+  nyq_re = q.ny0 * cs;
+}
+
 template <int IN_MODE>
 __device__ __forceinline__ void load_spectrum(const InvParams& p, long long f, int lane, float2 (&v)[8], float& nyq_re) {
-  if (IN_MODE == IN_COMPLEX) {
-    const float2* row = p.X + f * F;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = row[lane + 64 * m];
-    nyq_re = row[512].x;  // broadcast load; only lane 0 uses it
-  } else {
-    const float* mrow = p.mag + f * F;
-    const float* prow = p.phase + f * F;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      float a = mrow[lane + 64 * m];
-      float s, c;
-      sincos_big(prow[lane + 64 * m], s, c);
-      v[m] = make_float2(a * c, a * s);
-    }
-    float s, c;
-    sincos_big(prow[512], s, c);
-    nyq_re = mrow[512] * c;
-  }
+  RawFrame<IN_MODE> q;
+  load_raw(p, f, lane, q);
+  raw_to_spectrum(q, v, nyq_re);
 }
 
 // one frame: spectrum -> windowed time samples y[m] = (x[2n], x[2n+1]) * w, n = lane + 64 m
@@ -443,16 +492,22 @@ __device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const 
 }
 
 // K3: irFFT + window + overlap-add (hop = 256 = N/4) + envelope division + centre trim.
-// A wave produces output hop-slots [j0, j1) of one clip, streaming over frames
-// j0-1 .. j1+1 with the four overlapping frames' partial sums in registers.
-template <int IN_MODE>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void istft1024_ola_kernel(InvParams p) {
-  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave + 512];
+// A wave produces output hop-slots [j0, j1) of one clip, streaming over frames j0-1 .. j1+1 with the four
+// overlapping frames' partial sums in registers.  Spectra are requested two frames ahead (8 KB per wave in
+// flight); the steady-state loop is branch-free so that the compiler's vmcnt accounting leaves those loads
+// and the previous outputs' stores in flight across iterations (a conditional load anywhere in the loop
+// collapses every wait to vmcnt(0)).
+template <int IN_MODE, int DEPTH, bool TWLDS>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void istft1024_ola_kernel(InvParams p) {
+  __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave + 512 + (TWLDS ? kTwiddleCount : 0)];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* win = lds_all + WAVES_PER_BLOCK * kFftLdsFloat2PerWave;
+  float2* twtab = win + 512;
   for (int i = threadIdx.x; i < 512; i += 64 * WAVES_PER_BLOCK) win[i] = reinterpret_cast<const float2*>(p.window)[i];
+  if (TWLDS)
+    for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * WAVES_PER_BLOCK) twtab[i] = p.tw[i];
   __syncthreads();
 
   const long long run = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -465,8 +520,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void istft1024_ola_kernel(Inv
   if (j1 > nslots) j1 = nslots;
   if (j0 >= j1) return;
 
-  Twiddles tw;
-  load_twiddles<true>(tw, p.tw, lane);
+  Twiddles tw_regs;
+  if (!TWLDS) load_twiddles<true>(tw_regs, p.tw, lane);
+  const LdsTwiddles<true> tw_lds = {twtab, lane};
+  auto synth = [&](float2 (&v)[8], float nyq) {
+    if (TWLDS) synth_frame(v, nyq, tw_lds, win, lds, lane);
+    else synth_frame(v, nyq, tw_regs, win, lds, lane);
+  };
 
   float2 acc[8];
 #pragma unroll
@@ -475,44 +535,92 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void istft1024_ola_kernel(Inv
   const long long fbase = b * p.T;
   float* yclip = p.y + b * (256 * nslots);
   long long t = (j0 > 0) ? j0 - 1 : 0;
-  const long long t_last = j1 + 1;  // inclusive; frames >= T contribute nothing
+  const long long t_last = j1 + 1;                                  // inclusive; frames >= T contribute nothing
+  const long long t_have = (t_last < p.T - 1) ? t_last : p.T - 1;   // last frame this run reads
 
-  float2 nxt[8];
-  float nxt_nyq = 0.f;
-  if (t < p.T) load_spectrum<IN_MODE>(p, fbase + t, lane, nxt, nxt_nyq);
+  RawFrame<IN_MODE> q0 = {}, q1 = {};   // frames t and t + 1
+  if (t <= t_have) load_raw(p, fbase + t, lane, q0);
+  if (t + 1 <= t_have) load_raw(p, fbase + t + 1, lane, q1);
+
   // accumulators start aligned with frame t: acc[m] covers padded samples t*256 + 2*(lane+64m)
-  for (; t <= t_last; ++t) {
-    if (t < p.T) {
-      float2 v[8];
+  auto consume = [&](const RawFrame<IN_MODE>& q) {
+    float2 v[8];
+    float nyq;
+    raw_to_spectrum(q, v, nyq);
+    synth(v, nyq);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = nxt[m];
-      float nyq = nxt_nyq;
-      if (t + 1 <= t_last && t + 1 < p.T) load_spectrum<IN_MODE>(p, fbase + t + 1, lane, nxt, nxt_nyq);
-      synth_frame(v, nyq, tw, win, lds, lane);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) acc[m] = cadd(acc[m], v[m]);
-    }
-    const long long j = t - 2;  // padded slot t is complete -> output slot j
-    if (j >= j0 && j < j1) {
-      // frames contributing to output slot j are j-1 .. j+2
-      int mask = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        long long tt = j - 1 + q;
-        if (tt >= 0 && tt < p.T) mask |= 1 << q;
-      }
-      const float2* env = reinterpret_cast<const float2*>(p.env + mask * 256);
-      float2* dst = reinterpret_cast<float2*>(yclip + j * 256);
-      float2 e0 = env[lane], e1 = env[lane + 64];
-      dst[lane] = make_float2(acc[0].x / e0.x, acc[0].y / e0.y);
-      dst[lane + 64] = make_float2(acc[1].x / e1.x, acc[1].y / e1.y);
-    }
-    // advance the accumulator window by one hop (= 2 register slots)
+    for (int m = 0; m < 8; ++m) acc[m] = cadd(acc[m], v[m]);
+  };
+  auto emit = [&](long long j, float2 e0, float2 e1) {
+    float2* dst = reinterpret_cast<float2*>(yclip + j * 256);
+    dst[lane] = make_float2(acc[0].x / e0.x, acc[0].y / e0.y);
+    dst[lane + 64] = make_float2(acc[1].x / e1.x, acc[1].y / e1.y);
+  };
+  auto advance = [&]() {   // one hop = two register slots
 #pragma unroll
     for (int m = 0; m < 6; ++m) acc[m] = acc[m + 2];
     acc[6] = make_float2(0.f, 0.f);
     acc[7] = make_float2(0.f, 0.f);
+  };
+  // edges of the run / of the clip: any frame or slot may be missing
+  auto generic_step = [&]() {
+    if (t <= t_have) {
+      const RawFrame<IN_MODE> cur = q0;
+      q0 = q1;
+      if (t + 2 <= t_have) load_raw(p, fbase + t + 2, lane, q1);
+      consume(cur);
+    }
+    const long long j = t - 2;  // padded slot t is complete -> output slot j, fed by frames j-1 .. j+2
+    if (j >= j0 && j < j1) {
+      int mask = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long tt = j - 1 + q;
+        if (tt >= 0 && tt < p.T) mask |= 1 << q;
+      }
+      const float2* env = reinterpret_cast<const float2*>(p.env + mask * 256);
+      emit(j, env[lane], env[lane + 64]);
+    }
+    advance();
+    ++t;
+  };
+
+  // steady state: frames t .. t+2 exist, slot t-2 belongs to this run and has all four contributors
+  long long fast_begin = j0 + 2 > 3 ? j0 + 2 : 3;
+  long long fast_end = (j1 + 1 < t_have - 2) ? j1 + 1 : t_have - 2;   // inclusive
+  while (t < fast_begin && t <= t_last) generic_step();
+  if (t <= fast_end) {
+    const float2* env15 = reinterpret_cast<const float2*>(p.env + 15 * 256);
+    const float2 e0 = env15[lane], e1 = env15[lane + 64];
+    if (DEPTH == 2) {
+      // two frames in flight, two frames per trip with q0 / q1 swapping roles
+      auto fast_step = [&](RawFrame<IN_MODE>& q) {
+        const RawFrame<IN_MODE> cur = q;
+        load_raw(p, fbase + t + 2, lane, q);
+        consume(cur);
+        emit(t - 2, e0, e1);
+        advance();
+        ++t;
+      };
+      while (t + 1 <= fast_end) {
+        fast_step(q0);
+        fast_step(q1);
+      }
+    } else {
+      // one frame in flight (q0 = frame t); q1 is re-requested by the generic tail
+      q1 = {};
+      for (; t <= fast_end; ++t) {
+        const RawFrame<IN_MODE> cur = q0;
+        load_raw(p, fbase + t + 1, lane, q0);
+        consume(cur);
+        emit(t - 2, e0, e1);
+        advance();
+      }
+      q1 = {};
+      if (t + 1 <= t_have) load_raw(p, fbase + t + 1, lane, q1);
+    }
   }
+  while (t <= t_last) generic_step();
 }
 
 // K5: irFFT + window, frames out (no overlap-add): RealtimeSTFT/RealtimeDGT.invert
@@ -560,6 +668,42 @@ static inline int num_cus() {
   return cus;
 }
 
+// wave slots the chip offers one kernel variant (occupancy x CUs), cached per variant by the caller
+template <typename K>
+static long long resident_waves(K kernel, int block_threads, size_t dyn_lds) {
+  struct Entry { const void* k; size_t lds; long long waves; };
+  static thread_local Entry cache[16];
+  static thread_local int n_cached = 0;
+  for (int i = 0; i < n_cached; ++i)
+    if (cache[i].k == (const void*)kernel && cache[i].lds == dyn_lds) return cache[i].waves;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_threads, dyn_lds) != hipSuccess || nb <= 0) nb = 2;
+  const long long waves = (long long)nb * (block_threads / 64) * num_cus();
+  if (n_cached < 16) cache[n_cached++] = {(const void*)kernel, dyn_lds, waves};
+  return waves;
+}
+
+// Split each of the B clips' `units` (frames / hop slots) into equal runs, one wave per run.  Every wave of a
+// streaming kernel takes the same time, so the launch costs ceil(waves / slots) rounds of (run length +
+// per-run overhead): 4096 waves on 3072 slots is two rounds, the second one a third full -- pick the run
+// count that minimises rounds x run length instead of aiming at a fixed wave count.
+static long long plan_units_per_run(long long B, long long units, long long slots, long long min_units,
+                                    long long overhead_units) {
+  long long best_upr = units, best_cost = -1;
+  long long max_runs = units / (min_units > 0 ? min_units : 1);
+  if (max_runs < 1) max_runs = 1;
+  for (long long runs = 1; runs <= max_runs; ++runs) {
+    const long long upr = (units + runs - 1) / runs;
+    const long long waves = B * ((units + upr - 1) / upr);
+    const long long cost = ((waves + slots - 1) / slots) * (upr + overhead_units);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best_upr = upr;
+    }
+  }
+  return best_upr;
+}
+
 int launch_stft1024_fwd(const float* x, long long B, long long L, long long clip_stride, long long T, int hop,
                         int center, const float* window, const float2* tw, float2* out, float* phase,
                         hipStream_t stream) {
@@ -594,28 +738,25 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     p.power2 = power2; p.feat_channel_major = feat_channel_major;
   }
   if (B * T == 0) return 0;
-  // ~16 waves per CU; runs of at least 24 frames so that the 3 extra segment loads of a run start stay < 5 %
-  long long target_waves = (long long)num_cus() * 16;
-  long long runs_per_clip = (target_waves + B - 1) / B;
-  if (runs_per_clip < 1) runs_per_clip = 1;
-  long long fpr = (T + runs_per_clip - 1) / runs_per_clip;
-  if (fpr < 24) fpr = 24;
-  if (fpr > T) fpr = T;
-  runs_per_clip = (T + fpr - 1) / fpr;
-  p.runs_per_clip = runs_per_clip;
-  p.frames_per_run = fpr;
-  long long waves = B * runs_per_clip;
-  long long blocks = (waves + FWD_WAVES - 1) / FWD_WAVES;
-  const dim3 grid((unsigned)blocks), block(64 * FWD_WAVES);
-  if (!bank) {
-    if (phase) hipLaunchKernelGGL((stft1024_h256_fwd_kernel<true, 0>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((stft1024_h256_fwd_kernel<false, 0>), grid, block, 0, stream, p);
-  } else if (out) {
-    if (phase) hipLaunchKernelGGL((stft1024_h256_fwd_kernel<true, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((stft1024_h256_fwd_kernel<false, 1>), grid, block, 0, stream, p);
-  } else {
-    hipLaunchKernelGGL((stft1024_h256_fwd_kernel<false, 2>), grid, block, 0, stream, p);
+  constexpr int NW = 4;   // 4 waves per block, twiddles in registers (8 waves + LDS twiddles measured 1-2 % slower)
+  size_t dyn_lds = 0;
+  if (bank) {
+    for (int q = 0; q < bank->n_passes; ++q) dyn_lds += (size_t)64 * bank->pass_len[q] * sizeof(float);
+    if (dyn_lds > kMaxBandFloats * sizeof(float)) return -2;
+    dyn_lds += (size_t)2 * 64 * bank->n_passes * sizeof(int);   // lane_start, lane_filter
   }
+  void (*kernel)(FwdRunParams) = nullptr;
+  if (!bank) kernel = phase ? stft1024_h256_fwd_kernel<true, 0, NW, false> : stft1024_h256_fwd_kernel<false, 0, NW, false>;
+  else if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, NW, false>;
+  else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, NW, false> : stft1024_h256_fwd_kernel<false, 1, NW, false>;
+  // runs of at least 24 frames so that the 3 extra segment loads of a run start stay < 5 % (counted as one
+  // frame of overhead per run)
+  const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
+  const long long fpr = plan_units_per_run(B, T, slots, 24, 1);
+  p.frames_per_run = fpr;
+  p.runs_per_clip = (T + fpr - 1) / fpr;
+  const long long waves = B * p.runs_per_clip;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((waves + NW - 1) / NW)), dim3(64 * NW), dyn_lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -626,22 +767,17 @@ int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, 
   p.B = B; p.T = T;
   const long long nslots = T - 1;
   if (B == 0 || nslots <= 0) return 0;
-  // choose the run length so that the grid has ~12 waves per CU but runs are >= 32 slots
-  long long target_waves = (long long)num_cus() * 12;
-  long long runs_per_clip = (target_waves + B - 1) / B;
-  if (runs_per_clip < 1) runs_per_clip = 1;
-  long long spr = (nslots + runs_per_clip - 1) / runs_per_clip;
-  if (spr < 32) spr = 32;
-  if (spr > nslots) spr = nslots;
-  runs_per_clip = (nslots + spr - 1) / spr;
-  p.runs_per_clip = runs_per_clip;
+  // two frames in flight per wave, twiddles in registers: 2 waves per SIMD.  (One frame in flight at 3 waves,
+  // or LDS twiddles at 3-4 waves, all land within 3 % of each other: the kernel sits on its memory floor.)
+  void (*kernel)(InvParams) = X ? istft1024_ola_kernel<IN_COMPLEX, 2, false> : istft1024_ola_kernel<IN_POLAR, 2, false>;
+  // runs of >= 32 hop slots: a run synthesises 3 frames more than it emits slots
+  const long long slots = resident_waves(kernel, 64 * WAVES_PER_BLOCK, 0);
+  const long long spr = plan_units_per_run(B, nslots, slots, 32, 3);
   p.slots_per_run = spr;
-  long long waves = B * runs_per_clip;
-  long long blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  if (X)
-    hipLaunchKernelGGL(istft1024_ola_kernel<IN_COMPLEX>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
-  else
-    hipLaunchKernelGGL(istft1024_ola_kernel<IN_POLAR>, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
+  p.runs_per_clip = (nslots + spr - 1) / spr;
+  const long long waves = B * p.runs_per_clip;
+  const long long blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -381,13 +381,13 @@ def stft_mel_forward(x, window, band, contrast=None, offset=None, scale=None, ep
     x = _f32c(x)
     B, L = x.shape
     T = 1 + L // 256
-    start, length, slot, wT = band.on(x.device)
+    lane_filter, lane_start, weights = band.on(x.device)
     N = band.N
     X = torch.empty((B, T, 513), dtype=torch.complex64, device=x.device) if want_spectrum else None
     phase = torch.empty((B, T, 513), dtype=torch.float32, device=x.device) if (want_phase and want_spectrum) else None
     feat = torch.empty((B, N, T) if channel_major else (B, T, N), dtype=torch.float32, device=x.device)
-    check(lib().at_stft_mel_forward(ptr(x), B, L, L, T, 1024, 256, ptr(window), ptr(start), ptr(length), ptr(slot),
-                                    ptr(wT), N, band.lpad, band.n_slots, band.slot_len.ctypes.data,
+    check(lib().at_stft_mel_forward(ptr(x), B, L, L, T, 1024, 256, ptr(window), ptr(lane_filter), ptr(lane_start),
+                                    ptr(weights), N, band.n_passes, band.pass_len.ctypes.data,
                                     contrast_code(contrast), int(power == 2),
                                     ptr(offset), ptr(scale), eps, ptr(X), ptr(phase), ptr(feat), int(channel_major),
                                     stream_ptr()), "at_stft_mel_forward")

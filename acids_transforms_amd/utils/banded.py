@@ -1,16 +1,110 @@
 """Banded view of a (K x N) filterbank for the fused STFT -> mel kernel.
 
 Mel filterbanks are banded: column n is zero outside a short run of frequency rows.  The fused
-forward kernel exploits exactly that (and nothing else): per filter it needs [start, start+len) and
-the weights inside.  Built on the host from the dense bank (one device->host copy per bank version),
-cached by the caller.  A bank that is not banded enough simply reports `eligible = False` and the
-dense MFMA projection (`at_mel_project`) is used instead.
+forward kernel exploits exactly that (and nothing else): after the FFT a wave holds |X| of one frame
+in its LDS slab, and every lane walks the band of one filter per *pass* (N <= 64 * passes), four
+bins per step (`ds_read_b128` of the magnitudes, `ds_read_b128` of the weights).  This module turns
+the dense bank into the three tables that walk needs -- built on the host, once per bank version,
+cached by the caller:
+
+  lane_filter[q*64 + l]   filter summed by lane l in pass q (-1: none)
+  lane_start [q*64 + l]   first bin of that lane's walk (multiple of 4)
+  weights                 pass-major, quad-major, lane-minor: the 4 weights lane l multiplies in step j
+                          of pass q sit at float offset ((quad_base[q] + j) * 64 + l) * 4
+
+so consecutive lanes read consecutive 16-byte slots of the weight table (conflict-free for any band
+length), and the magnitudes are the only access whose banking depends on the bank itself.  A
+`ds_read_b128` is served in four groups of 16 lanes; two lanes of a group collide when they read
+different 16-byte slots that are congruent mod 256 bytes.  The lane assignment below therefore picks,
+per group, filters whose band starts fall on distinct slots (mod 16); a filter shorter than its
+pass's walk may start up to `slack` quads early (zero weights in front), which is what makes a
+collision-free choice exist in practice.  `lds_read_cycles()` evaluates the result with the same
+banking model, so the property is testable without a GPU.
+
+A bank that is not banded enough reports `eligible = False` and the dense MFMA projection
+(`at_mel_project`) is used instead.
 """
 import numpy as np
 import torch
 
-MAX_SLOTS = 4        # filters per lane (N <= 256)
-MAX_BAND = 128       # longest band a lane will walk
+MAX_PASSES = 4        # filters per lane (N <= 256)
+MAX_BAND = 128        # longest band a lane will walk
+MAX_TABLE_FLOATS = 8192   # LDS copy of the weights (kMaxBandFloats in stft1024.hip), dynamic LDS
+# lanes served together by one LDS cycle of a ds_read_b128 (MI355X_MICROARCH.md, LDS table)
+B128_GROUPS = (
+    (0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27),
+    (4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31),
+    (32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59),
+    (36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63),
+)
+
+
+def _pass_cycles(lane_quad, walk_quads):
+    """LDS cycles of one pass's magnitude reads (ds_read_b128 banking model) and the conflict-free minimum."""
+    cycles = 0
+    for j in range(walk_quads):
+        for lanes in B128_GROUPS:
+            per_residue = {}
+            for lane in lanes:
+                per_residue.setdefault(int(lane_quad[lane] + j) % 16, set()).add(int(lane_quad[lane] + j))
+            cycles += max(len(v) for v in per_residue.values())
+    return cycles, walk_quads * len(B128_GROUPS)
+
+
+def _assign_pass_once(filters, first_quad, n_quads, walk_quads, rng):
+    lane_filter = np.full(64, -1, np.int64)
+    lane_quad = np.zeros(64, np.int64)
+    taken = [dict() for _ in B128_GROUPS]       # residue (slot mod 16) -> absolute slot
+    used = [0] * len(B128_GROUPS)
+    slack = {f: min(walk_quads - n_quads[f], first_quad[f]) for f in filters}
+    noise = {f: (rng.random() if rng is not None else 0.0) for f in filters}
+    for f in sorted(filters, key=lambda f: (slack[f], noise[f], f)):     # least freedom first
+        choice = None
+        shifts = list(range(slack[f] + 1))
+        if rng is not None:
+            rng.shuffle(shifts)
+        for d in shifts:
+            quad = first_quad[f] - d
+            for g in sorted(range(len(B128_GROUPS)), key=lambda g: (used[g], noise[f] * (g + 1) % 1.0)):
+                if used[g] < 16 and taken[g].get(quad % 16, quad) == quad:
+                    choice = (g, quad)
+                    break
+            if choice:
+                break
+        if choice is None:                                      # collision: least loaded group, no shift
+            g = min((g for g in range(len(B128_GROUPS)) if used[g] < 16), key=lambda g: used[g])
+            choice = (g, first_quad[f])
+        g, quad = choice
+        lane = B128_GROUPS[g][used[g]]
+        used[g] += 1
+        taken[g].setdefault(quad % 16, quad)
+        lane_filter[lane], lane_quad[lane] = f, quad
+    # idle lanes still issue the reads: park each on a slot nobody else in its group uses
+    for g, lanes in enumerate(B128_GROUPS):
+        for lane in lanes[used[g]:]:
+            free = [r for r in range(16) if r not in taken[g]]
+            quad = free[0] if free else 0
+            taken[g].setdefault(quad % 16, quad)
+            lane_quad[lane] = quad
+    return lane_filter, lane_quad
+
+
+def _assign_pass(filters, first_quad, n_quads, walk_quads, tries=64):
+    """Place the filters of one pass on the 64 lanes.  Returns (lane_filter[64], lane_quad[64]):
+    lane_quad is the 16-byte slot index (bin // 4) at which the lane's walk starts.  Greedy, least
+    freedom first; if the plain order leaves collisions, a few seeded random tie-breaks are tried and
+    the cheapest placement under the banking model is kept (deterministic for a given bank)."""
+    best = None
+    rng = None
+    for attempt in range(tries):
+        lf, lq = _assign_pass_once(filters, first_quad, n_quads, walk_quads, rng)
+        cycles, ideal = _pass_cycles(lq, walk_quads)
+        if best is None or cycles < best[0]:
+            best = (cycles, lf, lq)
+        if cycles == ideal:
+            break
+        rng = np.random.default_rng(1234 + attempt)
+    return best[1], best[2]
 
 
 class BandedBank:
@@ -23,42 +117,61 @@ class BandedBank:
         has = nz.any(0)
         first = np.where(has, nz.argmax(0), 0)
         last = np.where(has, K - 1 - nz[::-1].argmax(0), -1)
-        first = (first // 4) * 4                     # bands start on a 16-byte boundary: ds_read_b128 walks
-        length = np.where(has, last - first + 1, 0).astype(np.int32)
-        self.lmax = int(length.max()) if N else 0
-        self.n_slots = (N + 63) // 64
-        # row length of the weight table: the longest band rounded up to whole 16-byte quads, and an odd number
-        # of quads -- lane l reads quad (l' * lpad/4 + j/4), an odd quad stride spreads 16 lanes over the
-        # 16 quad slots of the 256-byte LDS bank row (conflict-free ds_read_b128)
-        lpad = max(4, (self.lmax + 3) // 4 * 4)
-        if (lpad // 4) % 2 == 0 and N * (lpad + 4) <= 4096:
-            lpad += 4
-        self.eligible = bool(0 < N and self.n_slots <= MAX_SLOTS and self.lmax <= MAX_BAND and N * lpad <= 4096)
-        if not self.eligible:
+        first_quad = (first // 4).astype(np.int64)            # walks start on a 16-byte boundary
+        n_quads = np.where(has, (last - first_quad * 4) // 4 + 1, 0).astype(np.int64)
+        self.lmax = int((n_quads * 4).max()) if N else 0
+        self.n_passes = (N + 63) // 64
+        self.executed_macs = int(np.where(has, last - first + 1, 0).sum())   # useful multiply-adds per frame
+        self.eligible = False
+        if not (0 < N and self.n_passes <= MAX_PASSES and self.lmax <= MAX_BAND):
             return
-        wT = np.zeros((N, lpad), np.float32)
-        for n in range(N):
-            if length[n] > 0:
-                wT[n, :length[n]] = b[first[n]:first[n] + length[n], n]
-        # lane assignment: filters sorted by band length; every other pass is reversed so that a lane
-        # that walks a long band in one pass gets a short one in the next
-        order = np.argsort(-length, kind="stable")
-        slot = np.full(self.n_slots * 64, -1, np.int32)
-        slot_len = np.zeros(4, np.int32)
-        for q in range(self.n_slots):
-            chunk = order[q * 64:(q + 1) * 64]
-            slot_len[q] = (int(length[chunk].max()) + 3) // 4 * 4 if len(chunk) else 0
-            if q & 1:
-                chunk = chunk[::-1]
-            slot[q * 64:q * 64 + len(chunk)] = chunk
-        self.slot_len = slot_len                         # host array handed to the C ABI
-        self.lpad = lpad
-        self.executed_macs = int(length.sum())          # multiply-adds per frame (vs K*N dense)
-        self._host = (first.astype(np.int32), length, slot, wT)
+        # passes: filters sorted by band length, 64 per pass, so that every pass walks bands of similar length
+        order = np.argsort(-n_quads, kind="stable")
+        pass_len = np.zeros(4, np.int32)
+        lane_filter = np.full(self.n_passes * 64, -1, np.int32)
+        lane_start = np.zeros(self.n_passes * 64, np.int32)
+        tables = []
+        for q in range(self.n_passes):
+            chunk = [int(f) for f in order[q * 64:(q + 1) * 64]]
+            walk = int(max(n_quads[f] for f in chunk))
+            pass_len[q] = 4 * walk
+            lf, lq = _assign_pass(chunk, first_quad, n_quads, walk)
+            lane_filter[q * 64:(q + 1) * 64] = lf
+            lane_start[q * 64:(q + 1) * 64] = 4 * lq
+            w = np.zeros((walk, 64, 4), np.float32)           # [step][lane][4 bins]
+            for lane in range(64):
+                f = lf[lane]
+                if f < 0:
+                    continue
+                lo = 4 * int(lq[lane])
+                hi = min(lo + 4 * walk, K)
+                col = np.zeros(4 * walk, np.float32)
+                col[:hi - lo] = b[lo:hi, f]
+                assert not b[:lo, f].any() and not b[hi:, f].any()
+                w[:, lane, :] = col.reshape(walk, 4)
+            tables.append(w.reshape(-1))
+        weights = np.concatenate(tables) if tables else np.zeros(0, np.float32)
+        if weights.size > MAX_TABLE_FLOATS or int(lane_start.max()) + int(pass_len.max()) > 640:
+            return
+        self.eligible = True
+        self.pass_len = pass_len                              # host array handed to the C ABI
+        self.walked_macs = 64 * int(pass_len.sum())           # multiply-adds issued per frame (incl. zeros)
+        self._host = (lane_filter, lane_start, weights)
         self._dev = {}
 
+    def lds_read_cycles(self):
+        """(LDS cycles of the magnitude reads per frame under the ds_read_b128 banking model, the
+        conflict-free minimum).  Equal means no bank conflicts."""
+        _, lane_start, _ = self._host
+        cycles = ideal = 0
+        for q in range(self.n_passes):
+            c, i = _pass_cycles(lane_start[q * 64:(q + 1) * 64] // 4, int(self.pass_len[q]) // 4)
+            cycles += c
+            ideal += i
+        return cycles, ideal
+
     def on(self, device):
-        """(start, len, slot, wT) tensors on `device`."""
+        """(lane_filter, lane_start, weights) tensors on `device`."""
         key = str(device)
         if key not in self._dev:
             self._dev[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in self._host)

@@ -57,18 +57,21 @@ int at_stft_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, i
 /* Fused forward for Compose(STFT|DGT -> Magnitude(mel)) and for MFCC (n_fft = 1024, hop = 256):
  * the same framing + rFFT kernel additionally emits normalise(contrast(|X|^p @ bank)) from registers, so
  * the spectrum is not re-read (spectral_repr.py:215-226 / mel.py:43-44,68-73 behind stft.py:98-104).
- * The bank is passed in banded form: filter n has its non-zero rows in [band_start[n], +band_len[n])
- * (band_start a multiple of 4, lpad a multiple of 4),
- * weights in band_wT[n*lpad .. ] (zero padded, n_filters*lpad <= 4096); band_slot[q*64 + lane] names the
- * filter lane handles in pass q (-1 none); slot_len_host[q] (HOST array, n_slots <= 4 ints, multiples of 4,
- * <= lpad) is the longest band of pass q.
- * Exact for any bank whose columns are zero outside their band (the host builds the bands from the dense
- * bank); dense banks use at_mel_project.  out_complex_or_null == NULL: features only (MFCC).
+ * The bank is passed in banded form, as the walk of the kernel's epilogue: in pass q (n_passes <= 4) lane l
+ * of a wavefront sums filter lane_filter[q*64 + l] (-1: none) over pass_len_host[q] bins starting at bin
+ * lane_start[q*64 + l]; both arrays are DEVICE int32[n_passes*64], pass_len_host is a HOST array of
+ * multiples of 4 (<= 128), lane_start entries are multiples of 4 with lane_start + pass_len <= 640.
+ * band_weights (DEVICE, 16-byte aligned): the 4 weights lane l applies in step j of pass q are the floats at
+ * ((quad_base[q] + j)*64 + l)*4, quad_base[q] = sum_{q' < q} pass_len[q']/4; zero outside the filter's band;
+ * 64 * sum(pass_len) <= 8192 floats.  (utils/banded.py builds these from a dense bank and chooses the lanes so
+ * that the LDS reads of the walk are bank-conflict free.)
+ * Exact for any bank whose columns are zero outside their band; dense banks use at_mel_project.
+ * out_complex_or_null == NULL: features only (MFCC).
  * feat: (B*T, n_filters), or (B, n_filters, T) when feat_channel_major. */
 int at_stft_mel_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
-                        const float *window, const int32_t *band_start, const int32_t *band_len,
-                        const int32_t *band_slot, const float *band_wT, int n_filters, int lpad, int n_slots,
-                        const int32_t *slot_len_host, int contrast, int power2, const float *offset, const float *scale, float eps,
+                        const float *window, const int32_t *lane_filter, const int32_t *lane_start,
+                        const float *band_weights, int n_filters, int n_passes, const int32_t *pass_len_host,
+                        int contrast, int power2, const float *offset, const float *scale, float eps,
                         float *out_complex_or_null, float *phase_or_null, float *feat, int feat_channel_major,
                         void *stream);
 

@@ -138,3 +138,39 @@ def test_melbank_properties():
     assert fb128.shape == (513, 128) and float(fb128.min()) >= 0 and float(fb128.max()) <= 1.0
     peaks = fb128[:, 5:].argmax(0)
     assert bool((peaks[1:] >= peaks[:-1]).all())          # centre frequencies increase
+
+
+def test_banded_bank_tables_reproduce_dense_bank_and_are_conflict_free():
+    """utils/banded.py: the walk tables handed to at_stft_mel_forward must (a) reproduce the dense contraction
+    exactly when replayed on the CPU and (b) keep the ds_read_b128 magnitude reads of the standard mel banks
+    free of LDS bank conflicts under the documented banking model."""
+    from acids_transforms_amd.utils.banded import BandedBank
+    from acids_transforms_amd.utils.melbank import melscale_fbanks
+    rng = np.random.default_rng(0)
+    for n_mels in (40, 64, 128, 256):
+        fb = melscale_fbanks(513, 0., 22050., n_mels, 44100)
+        band = BandedBank(fb)
+        assert band.eligible and band.n_passes == (n_mels + 63) // 64
+        lane_filter, lane_start, weights = band._host
+        assert weights.size == 64 * int(band.pass_len.sum()) <= 8192
+        assert (lane_start % 4 == 0).all() and int(lane_start.max()) + int(band.pass_len.max()) <= 640
+        assert sorted(int(f) for f in lane_filter if f >= 0) == list(range(n_mels))
+        mag = np.zeros(640, np.float32)
+        mag[:513] = rng.random(513).astype(np.float32)
+        feat = np.zeros(n_mels, np.float64)
+        base = 0
+        for q in range(band.n_passes):
+            steps = int(band.pass_len[q]) // 4
+            w = weights[base * 256:(base + steps) * 256].reshape(steps, 64, 4)
+            for lane in range(64):
+                f = lane_filter[q * 64 + lane]
+                if f >= 0:
+                    s0 = lane_start[q * 64 + lane]
+                    feat[f] = float((mag[s0:s0 + 4 * steps].astype(np.float64) * w[:, lane, :].reshape(-1)).sum())
+            base += steps
+        want = mag[:513].astype(np.float64) @ fb.double().numpy()
+        assert np.allclose(feat, want, rtol=1e-12, atol=1e-12)
+        cycles, ideal = band.lds_read_cycles()
+        assert cycles <= ideal + 2, (n_mels, cycles, ideal)
+    dense = BandedBank(torch.rand(513, 32))
+    assert not dense.eligible                                  # not banded: the MFMA projection is used instead

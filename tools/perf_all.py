@@ -44,6 +44,14 @@ if "mel128" in which:
 if "mel513" in which:
     mg = A.Magnitude(mode=None).to(dev)
     report("mel513", timeit(lambda: mg(X), n=5), 4104 + 2052, 2 * 513 * 513)
+if "fused" in which or "fused2" in which:
+    mgf = A.Magnitude(n_mels=128, mode="unipolar", contrast="log1p").to(dev)
+    mgf.scale_data(X[:8])
+    if "fused" in which:
+        report("fwd+mel fused", timeit(lambda: mgf.forward_fused(m, x, return_spectrum=True)), 5640)
+    if "fused2" in which:
+        mf = A.MFCC().to(dev)   # features only: the spectrum never reaches HBM
+        report("fwd+mel (no X)", timeit(lambda: mf(x)), 1024 + 512)
 if "polar" in which:
     mag, ph = X.abs(), X.angle()
     report("istft_polar", timeit(lambda: m._istft(mag=mag, phase=ph)), 5128)
