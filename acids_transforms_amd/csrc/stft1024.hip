@@ -197,8 +197,11 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
 // MEL: 0 = spectrum only; 1 = spectrum + fused banded-filterbank features; 2 = features only.
 // FWD_WAVES waves per workgroup share the LDS constant tables (twiddles are always staged there; TWLDS makes
 // the FFT read them at the point of use instead of holding 44 VGPRs, which buys a fourth wave per SIMD).
-template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS>
-__global__ __launch_bounds__(64 * FWD_WAVES, TWLDS ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
+// CMBUF (MEL != 0, channel-major features): number of passes whose outputs are kept for eight frames in
+// registers and written as 32 contiguous bytes per filter; 0 = every frame scatters 4-byte stores (each
+// lane its own row of the (B, N, T) tensor), which leaves partly written lines to be evicted and re-fetched.
+template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0>
+__global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
   __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
   extern __shared__ float4 band_lds[];   // MEL != 0: the bank's weight table, sized by the launcher
@@ -265,6 +268,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, TWLDS ? 4 : 3) void stft1024_h256_f
   float* prow = WRITE_PHASE ? p.phase + (b * p.T + t0) * F : nullptr;
   float* frow = (MEL != 0) ? p.feat + (b * p.T + t0) * (long long)p.bank.n_filters : nullptr;
   long long t_cur = t0;
+  float cm[CMBUF ? CMBUF : 1][8];   // features of frames t_cur-7 .. t_cur (sliding), one row per pass
+#pragma unroll
+  for (int q = 0; q < (CMBUF ? CMBUF : 1); ++q)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cm[q][k] = 0.f;
   float mel_off = 0.f, mel_sc = 1.f;
   if (MEL != 0 && p.offset) {
     mel_off = *p.offset;
@@ -344,8 +352,31 @@ __global__ __launch_bounds__(64 * FWD_WAVES, TWLDS ? 4 : 3) void stft1024_h256_f
         if (f >= 0) {
           acc = fwd_contrast(acc, p.contrast, p.eps);
           if (p.offset) acc = (acc - mel_off) / mel_sc;
-          if (p.feat_channel_major) p.feat[((long long)b * p.bank.n_filters + f) * p.T + t_cur] = acc;
-          else frow[f] = acc;
+          if (CMBUF) {
+            if (q < CMBUF) {
+#pragma unroll
+              for (int k = 0; k < 7; ++k) cm[q][k] = cm[q][k + 1];
+              cm[q][7] = acc;
+            }
+          } else if (p.feat_channel_major) {
+            p.feat[((long long)b * p.bank.n_filters + f) * p.T + t_cur] = acc;
+          } else {
+            frow[f] = acc;
+          }
+        }
+        if (CMBUF && q < CMBUF && ((t_cur & 7) == 7 || t_cur == t1 - 1) && f >= 0) {
+          // frames [first, t_cur] of the window are new since the last flush (or the start of the run)
+          long long first = t_cur & ~7LL;
+          if (first < t0) first = t0;
+          float* dst = p.feat + ((long long)b * p.bank.n_filters + f) * p.T + (t_cur - 7);
+          if (first == t_cur - 7 && !(p.T & 1)) {         // whole group, rows 8-byte aligned
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) *reinterpret_cast<float2*>(dst + k) = make_float2(cm[q][k], cm[q][k + 1]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (t_cur - 7 + k >= first) dst[k] = cm[q][k];
+          }
         }
       }
       wave_lds_sync();
@@ -738,17 +769,26 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     p.power2 = power2; p.feat_channel_major = feat_channel_major;
   }
   if (B * T == 0) return 0;
-  constexpr int NW = 4;   // 4 waves per block, twiddles in registers (8 waves + LDS twiddles measured 1-2 % slower)
   size_t dyn_lds = 0;
   if (bank) {
     for (int q = 0; q < bank->n_passes; ++q) dyn_lds += (size_t)64 * bank->pass_len[q] * sizeof(float);
     if (dyn_lds > kMaxBandFloats * sizeof(float)) return -2;
     dyn_lds += (size_t)2 * 64 * bank->n_passes * sizeof(int);   // lane_start, lane_filter
   }
+  // plain forward: 4 waves per block, twiddles in registers (3 waves per SIMD).  Fused: 8 waves share the band
+  // table and read their twiddles from a workgroup LDS copy, which frees 44 VGPRs for a 4th wave per SIMD to
+  // cover the epilogue's LDS round trips (4 % faster than the 3-wave form, A/B on one device).
+  int NW = 4;
   void (*kernel)(FwdRunParams) = nullptr;
-  if (!bank) kernel = phase ? stft1024_h256_fwd_kernel<true, 0, NW, false> : stft1024_h256_fwd_kernel<false, 0, NW, false>;
-  else if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, NW, false>;
-  else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, NW, false> : stft1024_h256_fwd_kernel<false, 1, NW, false>;
+  if (!bank) {
+    kernel = phase ? stft1024_h256_fwd_kernel<true, 0, 4, false> : stft1024_h256_fwd_kernel<false, 0, 4, false>;
+  } else {
+    NW = 8;
+    if (!out && feat_channel_major && bank->n_passes == 1) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 1>;
+    else if (!out && feat_channel_major && bank->n_passes == 2) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 2>;
+    else if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true>;
+    else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true> : stft1024_h256_fwd_kernel<false, 1, 8, true>;
+  }
   // runs of at least 24 frames so that the 3 extra segment loads of a run start stay < 5 % (counted as one
   // frame of overhead per run)
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);

@@ -52,6 +52,9 @@ if "fused" in which or "fused2" in which:
     if "fused2" in which:
         mf = A.MFCC().to(dev)   # features only: the spectrum never reaches HBM
         report("fwd+mel (no X)", timeit(lambda: mf(x)), 1024 + 512)
+if "fusedraw" in which:
+    mgr = A.Magnitude(n_mels=128, mode=None, contrast=None).to(dev)
+    report("fwd+mel raw", timeit(lambda: mgr.forward_fused(m, x, return_spectrum=True)), 5640)
 if "polar" in which:
     mag, ph = X.abs(), X.angle()
     report("istft_polar", timeit(lambda: m._istft(mag=mag, phase=ph)), 5128)
