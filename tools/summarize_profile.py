@@ -22,7 +22,12 @@ def short(name):
 
 
 print("# rocprofv3 summary `%s`\n" % tag)
-print("Command: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras` (B=1024 clips x 4 s, 1 GPU)\n")
+STEPS, WARM = int(os.environ.get("PROFILE_STEPS", "20")), int(os.environ.get("PROFILE_WARMUP", "5"))
+print("Command: `python3 bench.py --steps %d --warmup %d --no-cpu-baseline --no-extras` (B=1024 clips x 4 s, 1 GPU)\n"
+      % (STEPS, WARM))
+print("`timed avg` = the launches of bench.py's timed region only (the last %d of a step kernel before the side "
+      "measurements): the first launches run on cold clocks and untouched pages and are what `avg` over all calls "
+      "adds to it.\n" % STEPS)
 kt = find("trace/**/*kernel_trace.csv")
 dur = defaultdict(list)
 if kt:
@@ -30,11 +35,12 @@ if kt:
         dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     total = sum(sum(v) for v in dur.values())
     print("## kernel trace (--kernel-trace --stats)\n")
-    print("| kernel | calls | avg us | min us | max us | total ms | % |")
-    print("|---|---|---|---|---|---|---|")
+    print("| kernel | calls | avg us | timed avg us | min us | max us | total ms | % |")
+    print("|---|---|---|---|---|---|---|---|")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:14]:
-        print("| `%s` | %d | %.1f | %.1f | %.1f | %.3f | %.1f |" % (k, len(v), sum(v) / len(v), min(v), max(v), sum(v) / 1e3,
-                                                             100 * sum(v) / total))
+        timed = v[WARM:WARM + STEPS] if len(v) >= WARM + STEPS else v
+        print("| `%s` | %d | %.1f | %.1f | %.1f | %.1f | %.3f | %.1f |" % (
+            k, len(v), sum(v) / len(v), sum(timed) / len(timed), min(v), max(v), sum(v) / 1e3, 100 * sum(v) / total))
     print()
 traffic = {}
 for name, patt, col in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv", "fetch"),
