@@ -31,6 +31,9 @@ _SIGNATURES = {
     "at_istft": [c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_sz, c_f],
     "at_irfft_frames": [c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f],
     "at_angle": [c_f, c_i64, c_f, c_f],
+    "at_phase_scan": [c_f, c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_f],
+    "at_phase_integrate": [c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f],
+    "at_polar_to_complex": [c_f, c_f, c_i64, c_f, c_f],
     "at_mel_project": [c_f, c_int, c_i64, c_i64, c_int, c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_flt, c_f, c_i64,
                        c_i64, c_f],
     "at_mag_pointwise": [c_f, c_int, c_i64, c_int, c_int, c_f, c_f, c_flt, c_f, c_f],

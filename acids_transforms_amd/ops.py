@@ -392,3 +392,60 @@ def stft_mel_forward(x, window, band, contrast=None, offset=None, scale=None, ep
                                     ptr(offset), ptr(scale), eps, ptr(X), ptr(phase), ptr(feat), int(channel_major),
                                     stream_ptr()), "at_stft_mel_forward")
     return X, phase, feat
+
+
+# ----------------------------------------------------------------------------------------------
+# phase-side representations (phase_repr.hip)
+# ----------------------------------------------------------------------------------------------
+SCAN_MODES = {"unwrap": 0, "forward": 1, "backward": 2, "central": 3, "angle": 4}
+
+
+def _btf(x):
+    if x.ndim < 2:
+        raise IndexError("expected (..., frames, bins), got shape %s" % (tuple(x.shape),))
+    T, F = x.shape[-2], x.shape[-1]
+    return x.numel() // max(T * F, 1) if T * F else 0, T, F
+
+
+def phase_scan(x, mode, frame_window=None, offset=None, scale=None, bare=False):
+    """Scan along dim -2 of x (..., T, F): complex64 spectrum (the angle is taken inside) or float32 phase.
+    mode: "angle" | "unwrap" | "forward" | "backward" | "central" (IF of the unwrapped phase, reference row
+    scaling included); bare=True: the plain fdiff_* of a real signal.  Optional per-frame weight (T,) and
+    Normalize affine are applied last.  Returns float32 of x's shape."""
+    if mode not in SCAN_MODES:
+        raise AttributeError("method %s not known" % mode)
+    require_device(x)
+    cplx = x.is_complex()
+    x = x.to(torch.complex64) if cplx else _f32c(x)
+    x = x if x.is_contiguous() else x.contiguous()
+    B, T, F = _btf(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if frame_window is not None:
+        frame_window = _f32c(frame_window.to(x.device))
+        assert frame_window.numel() == T
+    check(lib().at_phase_scan(ptr(x) if cplx else None, None if cplx else ptr(x), B, T, F, SCAN_MODES[mode], int(bare),
+                              ptr(frame_window), ptr(offset), ptr(scale), ptr(out), stream_ptr()), "at_phase_scan")
+    return out
+
+
+def phase_integrate(y, method, offset=None, scale=None, rescale=True):
+    """IF.invert's tail: (de-normalise,) undo the row scaling of `method` (rescale) and integrate along dim -2."""
+    if method not in ("forward", "backward", "central"):
+        raise AttributeError("method %s not known" % method)
+    require_device(y)
+    y = _f32c(y)
+    B, T, F = _btf(y)
+    out = torch.empty_like(y)
+    check(lib().at_phase_integrate(ptr(y), B, T, F, SCAN_MODES[method], int(rescale), ptr(offset), ptr(scale), ptr(out),
+                                   stream_ptr()), "at_phase_integrate")
+    return out
+
+
+def polar_to_complex(mag, phase):
+    """mag * exp(1j * phase) as complex64."""
+    require_device(mag, phase)
+    mag, phase = torch.broadcast_tensors(mag, phase)
+    mag, phase = _f32c(mag), _f32c(phase)
+    out = torch.empty(mag.shape, dtype=torch.complex64, device=mag.device)
+    check(lib().at_polar_to_complex(ptr(mag), ptr(phase), mag.numel(), ptr(out), stream_ptr()), "at_polar_to_complex")
+    return out

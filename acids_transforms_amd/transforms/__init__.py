@@ -4,6 +4,7 @@ from .stft import STFT, RealtimeSTFT
 from .dgt import DGT, RealtimeDGT
 from .norm import Normalize
 from .spectral_repr import Magnitude
+from .phase_repr import Real, Imaginary, Phase, IF, SpectralRepresentation, Cartesian, Polar, PolarIF
 from .mel import MFCC
 from .oadd import OverlapAdd
 from .raw import MuLaw
@@ -11,4 +12,5 @@ from .misc import OneHot
 
 __all__ = ["AudioTransform", "ComposeAudioTransform", "NotInvertibleError", "InversionEnumType",
            "apply_transform_to_list", "apply_invert_transform_to_list", "STFT", "RealtimeSTFT", "DGT", "RealtimeDGT",
-           "Normalize", "Magnitude", "MFCC", "OverlapAdd", "MuLaw", "OneHot"]
+           "Normalize", "Magnitude", "Real", "Imaginary", "Phase", "IF", "SpectralRepresentation", "Cartesian", "Polar",
+           "PolarIF", "MFCC", "OverlapAdd", "MuLaw", "OneHot"]

@@ -199,6 +199,28 @@ int at_onehot(const int64_t *x, int64_t n, int classes, int64_t channel_major_in
 /* Tensor.argmax(-1) (misc.py:188-189): first index of the row maximum. */
 int at_argmax_last(const int64_t *x_i64, const float *x_f32, int64_t rows, int cols, int64_t *out, void *stream);
 
+/* ---- phase-side representations ------------------------------------------ */
+/* Scan along the frame axis of a (B, T, F) spectrum, one of X_complex / phase given (the angle is taken
+ * inside), optional per-frame weight frame_window[T] and Normalize affine (device scalars) applied last:
+ *   mode 0  unwrap(angle)                      utils/misc.py:12-26   (Phase(unwrap=True), spectral_repr.py:271-274)
+ *   mode 1  IF "forward"   fdiff_forward(unwrap)/pi   rows [0, T-2]   utils/misc.py:65-68, spectral_repr.py:323-325
+ *   mode 2  IF "backward"  fdiff_backward(unwrap)/-pi rows [1, T-1]   utils/misc.py:71-75, spectral_repr.py:320-322
+ *   mode 3  IF "central"   fdiff_central(unwrap)/2pi  rows [1, T-2]   utils/misc.py:77-81, spectral_repr.py:326-328
+ *   mode 4  angle only                                                   (Phase(unwrap=False))
+ * bare != 0 (modes 1-3, real input in `phase`): the plain fdiff_* of utils/misc.py:65-81, no unwrap, no division.
+ * Sequential in t per (clip, bin) column with torch's CPU arithmetic (double cumsum accumulator). */
+int at_phase_scan(const float *X_complex, const float *phase, int64_t B, int64_t T, int64_t F, int mode, int bare,
+                  const float *frame_window, const float *offset, const float *scale, float *out, void *stream);
+
+/* IF.invert (spectral_repr.py:360-373): de-normalise (offset/scale may be NULL), undo the per-row scaling of
+ * `method` (1 forward, 2 backward, 3 central; skipped when rescale == 0: the bare fint_* of utils/misc.py:83-104)
+ * and integrate along t.  out != y. */
+int at_phase_integrate(const float *y, int64_t B, int64_t T, int64_t F, int method, int rescale, const float *offset,
+                       const float *scale, float *out, void *stream);
+
+/* mag * exp(i * phase) -> complex64 (SpectralRepresentation.invert, spectral_repr.py:449-451). */
+int at_polar_to_complex(const float *mag, const float *phase, int64_t n, float *out_complex, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

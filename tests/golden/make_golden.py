@@ -437,9 +437,100 @@ def g10():
     save("g10_agogo", x=x, X_stft=X, mag_dgt=mag, phase_pghi=phase, y_pghi=y, y_stft=s.invert(X))
 
 
+# --------------------------------------------------------------------------
+# G11: phase-side representations: unwrap, finite differences /
+# integrations, Phase, IF, Real/Imaginary and the stacked Cartesian / Polar / PolarIF
+# --------------------------------------------------------------------------
+def g11():
+    import acids_transforms.utils.misc as ref_misc
+    out = {}
+    g = torch.Generator().manual_seed(110)
+    # finite-difference / integration helpers on plain real input, odd and even frame counts
+    for T in (10, 11):
+        r = torch.randn(2, T, 7, generator=g)
+        out["r%d" % T] = r
+        out["unwrap%d" % T] = ref_misc.unwrap(r * 3.0)
+        for name in ("forward", "backward", "central"):
+            out["fdiff_%s%d" % (name, T)] = getattr(ref_misc, "fdiff_" + name)(r.clone())
+            out["fint_%s%d" % (name, T)] = getattr(ref_misc, "fint_" + name)(r.clone())
+    # spectra: STFT of a tonal + noise mix (phase advances steadily -> many wraps) and a random one
+    x = torch.stack([sig_tonal(1024) + 0.05 * sig_noise((1024,), 111), sig_noise((1024,), 112)])
+    X = at.STFT(n_fft=128, hop_length=32)(x)                      # (2, 33, 65)
+    Xr = (torch.randn(1, 6, 513, generator=g) * torch.exp(2j * np.pi * torch.rand(1, 6, 513, generator=g))).to(torch.complex64)
+    out["x"] = x
+    out["X"] = X
+    out["Xr"] = Xr
+    out["unwrap_angle_X"] = ref_misc.unwrap(X.angle())
+    for tag, spec in (("X", X), ("Xr", Xr)):
+        for mode in (("none", "bipolar", "gaussian") if tag == "X" else ("gaussian",)):
+            for unwrap in (False, True):
+                for keep in ((True, False) if mode == "none" else (True,)):
+                    ph = at.Phase(mode=mode, unwrap=unwrap, keep_nyquist=keep)
+                    ph.scale_data(spec)
+                    key = "phase_%s_%s_%d_%d" % (tag, mode, int(unwrap), int(keep))
+                    y = ph(spec)
+                    out[key] = y
+                    out[key + "_inv"] = ph.invert(y.clone())
+                    if mode != "none":
+                        out[key + "_offset"] = ph.norm.offset
+                        out[key + "_scale"] = ph.norm.scale
+            for method in ("forward", "backward", "central"):
+                for keep in ((True, False) if mode == "none" else (True,)):
+                    f = at.IF(mode=mode, method=method, keep_nyquist=keep)
+                    f.scale_data(spec)
+                    key = "if_%s_%s_%s_%d" % (tag, mode, method, int(keep))
+                    y = f(spec)
+                    out[key] = y
+                    out[key + "_inv"] = f.invert(y.clone())
+                    if mode != "none":
+                        out[key + "_offset"] = f.norm.offset
+                        out[key + "_scale"] = f.norm.scale
+        # weighted IF: the reference caches a 1-D window and then asks it for size(-2), so only the first
+        # get_if call of an object works; record that first call and whether the second one raises
+        for method in ("forward", "backward", "central"):
+            f = at.IF(mode="none", method=method, weighted=True)
+            out["ifw_%s_%s" % (tag, method)] = f.get_if(spec)
+            try:
+                f.get_if(spec)
+                out["ifw_second_call_raises"] = np.asarray(0)
+            except IndexError:
+                out["ifw_second_call_raises"] = np.asarray(1)
+        for mode in (("none", "gaussian") if tag == "X" else ()):
+            for cls, name in ((at.Real, "real"), (at.Imaginary, "imag")):
+                for keep in (True, False):
+                    rr = cls(mode=mode, keep_nyquist=keep)
+                    rr.scale_data(spec)
+                    key = "%s_%s_%s_%d" % (name, tag, mode, int(keep))
+                    y = rr(spec)
+                    out[key] = y
+                    out[key + "_inv"] = rr.invert(y.clone())
+    # stacked representations, default arguments (bank injected: the shim has no mel arithmetic of its own)
+    bank = torch.rand(65, 65, generator=g) * (torch.rand(65, 65, generator=g) < 0.1)
+    taf._INJECTED_BANK = bank
+    out["bank65"] = bank
+    for name, ctor in (("cartesian", lambda **kw: at.Cartesian(**kw)),
+                       ("polar", lambda **kw: at.Polar(magnitude_args={"mode": "bipolar", "n_fft": 128}, **kw)),
+                       ("polarif", lambda **kw: at.PolarIF(magnitude_args={"mode": "bipolar", "n_fft": 128}, **kw))):
+        for stack in (-2, None):
+            for keep in (True, False):
+                if name != "cartesian" and not keep:
+                    continue      # Magnitude(keep_nyquist=False) builds a 64-point scale against a 65-bin bank
+                t = ctor(stack=stack, keep_nyquist=keep)
+                t.scale_data(X)
+                y = t(X)
+                key = "%s_%s_%d" % (name, "none" if stack is None else "m2", int(keep))
+                if stack is None:
+                    out[key + "_a"], out[key + "_b"] = y
+                else:
+                    out[key] = y
+                out[key + "_inv"] = t.invert(y if stack is None else y.clone())
+    taf._INJECTED_BANK = None
+    save("g11_phase_repr", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10"]
-    table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10}
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11"]
+    table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11}
     for w in which:
         print("==", w)
         table[w]()

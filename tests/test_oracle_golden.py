@@ -211,3 +211,57 @@ def test_unpinned_restatements_are_sane():
     import scipy.fft
     m = torch.rand(5, 128)
     assert np.allclose(O.mfcc_dct(m, 40).numpy(), scipy.fft.dct(m.numpy(), type=2, norm="ortho")[:, :40], atol=1e-5)
+
+
+def test_phase_representations(golden):
+    """oracle unwrap / fdiff / fint / IF / Phase restatements against the reference's own outputs (G11).
+    Same torch CPU ops in the same order: equality up to libm differences of atan2 between hosts."""
+    g = golden("g11_phase_repr")
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    for T in (10, 11):
+        r = t("r%d" % T)
+        assert torch.equal(O.unwrap(r * 3.0), t("unwrap%d" % T))
+        for m in ("forward", "backward", "central"):
+            assert torch.equal(O.fdiff(r, m), t("fdiff_%s%d" % (m, T)))
+            assert torch.equal(O.fint(r, m), t("fint_%s%d" % (m, T)))
+    assert int(g["ifw_second_call_raises"]) == 1      # the reference's weighted IF only survives one call
+    for tag in ("X", "Xr"):
+        X = t(tag)
+        close = lambda a, b: torch.allclose(a, b, rtol=2e-6, atol=2e-5)  # noqa: E731
+        if tag == "X":
+            assert close(O.unwrap(X.angle()), t("unwrap_angle_X"))
+        for m in ("forward", "backward", "central"):
+            assert close(O.inst_freq(X, m, True), t("ifw_%s_%s" % (tag, m)))
+            for mode in (("none", "gaussian", "bipolar") if tag == "X" else ("gaussian",)):
+                key = "if_%s_%s_%s_1" % (tag, mode, m)
+                raw = O.inst_freq(X, m)
+                off = sc = None
+                if mode != "none":
+                    off, sc = t(key + "_offset"), t(key + "_scale")
+                    o2, s2 = O.normalize_stats(raw, mode)
+                    assert torch.allclose(o2, off, rtol=1e-5, atol=1e-6) and torch.allclose(s2, sc, rtol=1e-5)
+                y = O.affine(raw, off, sc)
+                assert close(y, t(key))
+                # inversion from the golden forward output: plain IEEE arithmetic, exact
+                inv = O.inst_freq_invert(O.affine(t(key), off, sc, inverse=True), m)
+                assert torch.equal(inv, t(key + "_inv"))
+            if tag == "X":
+                y0 = O.drop_first_bin(O.inst_freq(X, m), False)
+                assert close(y0, t("if_X_none_%s_0" % m))
+                inv0 = O.pad_last_bin(O.inst_freq_invert(t("if_X_none_%s_0" % m), m), False)
+                assert torch.equal(inv0, t("if_X_none_%s_0_inv" % m))
+        for unwrap in (0, 1):
+            for mode in (("none", "gaussian", "bipolar") if tag == "X" else ("gaussian",)):
+                key = "phase_%s_%s_%d_1" % (tag, mode, unwrap)
+                off = sc = None
+                if mode != "none":
+                    off, sc = t(key + "_offset"), t(key + "_scale")
+                assert close(O.affine(O.phase_raw(X, bool(unwrap)), off, sc), t(key))
+                assert torch.equal(O.affine(t(key), off, sc, inverse=True), t(key + "_inv"))
+    X = t("X")
+    assert torch.equal(O.pad_last_bin(t("phase_X_none_1_0"), False), t("phase_X_none_1_0_inv"))
+    assert torch.equal(X.real, t("real_X_none_1")) and torch.equal(X.imag[..., 1:], t("imag_X_none_0"))
+    # stacked: Polar = (Magnitude, Phase) on dim -2; inversion = mag * exp(i phase)
+    P = t("polar_m2_1")
+    assert P.shape == X.shape[:-1] + (2, X.shape[-1])
+    assert torch.allclose(t("polar_none_1_a"), P.select(-2, 0)) and torch.allclose(t("polar_none_1_b"), P.select(-2, 1))

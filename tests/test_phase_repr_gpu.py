@@ -1,0 +1,186 @@
+"""GPU parity: phase-side representations (unwrap, IF, Phase, Real/Imaginary, Cartesian/Polar/PolarIF) through
+the C ABI (at_phase_scan / at_phase_integrate / at_polar_to_complex) against the reference's own outputs
+(tests/golden/g11_phase_repr.npz) and the oracle.
+
+Bars: everything downstream of a *real* input (unwrap / fdiff / fint of given numbers, IF.invert) is plain
+IEEE fp32 + a double cumsum accumulator, reproduced operation by operation -> bit-exact.  Paths that start from
+a complex spectrum go through atan2f, whose last bit differs between libms -> 1e-5 of the output's largest
+magnitude (the north_star fp32 tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+import acids_transforms_amd as A
+from acids_transforms_amd import ops
+from acids_transforms_amd.utils import misc as M
+from conftest import rel_max
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+T_ = torch.from_numpy
+METHODS = ("forward", "backward", "central")
+
+
+def cpu(t):
+    return t.detach().cpu()
+
+
+def test_scan_helpers_bit_exact(golden, dev):
+    g = golden("g11_phase_repr")
+    for T in (10, 11):
+        r = T_(g["r%d" % T]).to(dev)
+        assert torch.equal(cpu(M.unwrap(r * 3.0)), T_(g["unwrap%d" % T]))
+        for m in METHODS:
+            assert torch.equal(cpu(getattr(M, "fdiff_" + m)(r)), T_(g["fdiff_%s%d" % (m, T)])), (m, T)
+            keep = r.clone()
+            assert torch.equal(cpu(getattr(M, "fint_" + m)(r)), T_(g["fint_%s%d" % (m, T)])), (m, T)
+            assert torch.equal(r, keep)                       # never in place
+    one = torch.randn(3, 1, 5, device=dev)
+    assert torch.equal(M.fdiff_central(one), torch.cat([one, one], -2))        # single-frame quirk
+    assert torch.equal(M.fdiff_forward(one), one) and torch.equal(M.fint_central(one), one)
+    # unwrap of the CPU angle (real input): exact
+    ang = T_(g["X"]).angle()
+    assert torch.equal(cpu(M.unwrap(ang.to(dev))), T_(g["unwrap_angle_X"]))
+
+
+def test_phase_and_if_golden(golden, dev):
+    g = golden("g11_phase_repr")
+    for tag in ("X", "Xr"):
+        X = T_(g[tag]).to(dev)
+        modes = ("none", "bipolar", "gaussian") if tag == "X" else ("gaussian",)
+        for mode in modes:
+            for unwrap in (0, 1):
+                for keep in ((1, 0) if mode == "none" else (1,)):
+                    key = "phase_%s_%s_%d_%d" % (tag, mode, unwrap, keep)
+                    ph = A.Phase(mode=mode, unwrap=bool(unwrap), keep_nyquist=bool(keep))
+                    ph.scale_data(X)
+                    if mode != "none":
+                        assert abs(float(ph.norm.offset) - float(g[key + "_offset"])) <= 1e-5 * max(1, abs(float(g[key + "_offset"])))
+                        assert abs(float(ph.norm.scale) - float(g[key + "_scale"])) <= 1e-5 * abs(float(g[key + "_scale"]))
+                    y = ph(X)
+                    assert y.shape == g[key].shape
+                    assert rel_max(cpu(y).numpy(), g[key]) < TOL, key
+                    inv = ph.invert(T_(g[key]).to(dev))
+                    assert rel_max(cpu(inv).numpy(), g[key + "_inv"]) < TOL, key
+            for m in METHODS:
+                for keep in ((1, 0) if mode == "none" else (1,)):
+                    key = "if_%s_%s_%s_%d" % (tag, mode, m, keep)
+                    f = A.IF(mode=mode, method=m, keep_nyquist=bool(keep))
+                    f.scale_data(X)
+                    y = f(X)
+                    assert y.shape == g[key].shape
+                    assert rel_max(cpu(y).numpy(), g[key]) < TOL, key
+                    yin = T_(g[key]).to(dev)
+                    before = yin.clone()
+                    if mode != "none":     # use the reference's statistics: inversion is then exact arithmetic
+                        f.norm.set_affine(T_(g[key + "_offset"]).to(dev), T_(g[key + "_scale"]).to(dev))
+                    inv = f.invert(yin)
+                    assert torch.equal(yin, before)
+                    assert torch.equal(cpu(inv), T_(g[key + "_inv"])), key
+        for m in METHODS:                 # weighted: first call as the reference, and it keeps working
+            f = A.IF(mode="none", method=m, weighted=True)
+            for _ in range(2):
+                assert rel_max(cpu(f.get_if(X)).numpy(), g["ifw_%s_%s" % (tag, m)]) < TOL
+    with pytest.raises(AttributeError):
+        A.IF(method="sideways").get_if(X)
+
+
+def test_real_imag_and_stacked_golden(golden, dev):
+    g = golden("g11_phase_repr")
+    X = T_(g["X"]).to(dev)
+    for mode in ("none", "gaussian"):
+        for cls, name in ((A.Real, "real"), (A.Imaginary, "imag")):
+            for keep in (1, 0):
+                key = "%s_X_%s_%d" % (name, mode, keep)
+                r = cls(mode=mode, keep_nyquist=bool(keep))
+                r.scale_data(X)
+                y = r(X)
+                assert rel_max(cpu(y).numpy(), g[key]) < TOL, key
+                assert rel_max(cpu(r.invert(T_(g[key]).to(dev))).numpy(), g[key + "_inv"]) < TOL, key
+    assert torch.equal(A.Imaginary(mode=None)(X.real.contiguous()), torch.zeros_like(X.real))
+    bank = T_(g["bank65"])
+
+    def build(name, stack, keep):
+        if name == "cartesian":
+            return A.Cartesian(stack=stack, keep_nyquist=keep).to(dev)
+        cls = A.Polar if name == "polar" else A.PolarIF
+        t = cls(magnitude_args={"mode": "bipolar", "n_fft": 128}, stack=stack, keep_nyquist=keep)
+        t.magnitude._set_bank(bank)          # the golden run injected this bank into the torchaudio shim
+        return t.to(dev)
+
+    for name in ("cartesian", "polar", "polarif"):
+        for stack in (-2, None):
+            for keep in ((True, False) if name == "cartesian" else (True,)):
+                t = build(name, stack, keep)
+                t.scale_data(X)
+                y = t(X)
+                key = "%s_%s_%d" % (name, "none" if stack is None else "m2", int(keep))
+                if stack is None:
+                    assert rel_max(cpu(y[0]).numpy(), g[key + "_a"]) < TOL and rel_max(cpu(y[1]).numpy(), g[key + "_b"]) < TOL
+                    yin = (T_(g[key + "_a"]).to(dev), T_(g[key + "_b"]).to(dev))
+                else:
+                    assert y.shape == g[key].shape
+                    assert rel_max(cpu(y).numpy(), g[key]) < TOL, key
+                    yin = T_(g[key]).to(dev)
+                inv = t.invert(yin)
+                assert inv.dtype == torch.complex64
+                # inversion is judged against the input spectrum's scale (the phases are O(100 rad) unwrapped)
+                assert rel_max(cpu(inv).numpy(), g[key + "_inv"]) < 2e-5, key
+    with pytest.raises(RuntimeError):
+        A.SpectralRepresentation(magnitude_transform=A.Magnitude, phase_transform=A.Phase)
+
+
+def test_against_oracle_random_shapes(dev):
+    """Ragged / tiny shapes and extra batch dims, complex input, all scan modes vs the oracle."""
+    gen = torch.Generator().manual_seed(5)
+    for shape in [(1, 1, 1), (2, 2, 3), (3, 7, 65), (2, 3, 4, 33), (5, 513), (1, 64, 513)]:
+        X = (torch.randn(*shape, generator=gen) * torch.exp(2j * np.pi * torch.rand(*shape, generator=gen))).to(torch.complex64)
+        Xd = X.to(dev)
+        assert rel_max(cpu(ops.phase_scan(Xd, "angle")).numpy(), X.angle().numpy()) < TOL
+        assert rel_max(cpu(ops.phase_scan(Xd, "unwrap")).numpy(), O.unwrap(X.angle()).numpy()) < TOL
+        for m in METHODS:
+            if m == "central" and shape[-2] == 1:
+                continue
+            for w in (False, True):
+                if w and shape[-2] == 1:
+                    continue            # the window's (N^2 - 1) denominator vanishes
+                want = O.inst_freq(X, m, weighted=w)
+                f = A.IF(mode=None, method=m, weighted=w)
+                assert rel_max(cpu(f(Xd)).numpy(), want.numpy()) < TOL, (shape, m, w)
+            y = torch.randn(*shape, generator=gen)
+            assert torch.equal(cpu(ops.phase_integrate(y.to(dev), m)), O.inst_freq_invert(y, m)), (shape, m)
+    mag, ph = torch.rand(4, 9, 17, generator=gen), (torch.rand(4, 9, 17, generator=gen) - 0.5) * 2e4
+    want = O.polar_to_complex(mag, ph)
+    got = cpu(ops.polar_to_complex(mag.to(dev), ph.to(dev)))
+    assert rel_max(torch.view_as_real(got).numpy(), torch.view_as_real(want).numpy()) < TOL
+    empty = torch.zeros(0, 4, 5, dtype=torch.complex64, device=dev)
+    assert ops.phase_scan(empty, "forward").shape == (0, 4, 5)
+    with pytest.raises(IndexError):
+        ops.phase_scan(torch.zeros(5, dtype=torch.complex64, device=dev), "unwrap")
+
+
+def test_full_size_round_trip_properties(dev):
+    """BASELINE config-2 size (1024 clips would be 1.4 GB per tensor; 256 clips x 690 frames x 513 bins here):
+    size-independent properties instead of an oracle run --
+      * fint_forward(fdiff_forward(u)) == u up to rounding, same for backward (exact inverses in exact arithmetic);
+      * IF("forward") -> invert reproduces unwrap(angle X);  exp(i unwrap) == exp(i angle);
+      * Polar -> invert reproduces X."""
+    B, T, F = 256, 690, 513
+    gen = torch.Generator(device=dev).manual_seed(11)
+    X = torch.view_as_complex(torch.randn(B, T, F, 2, device=dev, generator=gen))
+    u = ops.phase_scan(X, "unwrap")
+    ang = ops.phase_scan(X, "angle")
+    assert float((torch.cos(u) - torch.cos(ang)).abs().max()) < 2e-3      # |u| reaches ~1e3 rad: fp32 ulp ~6e-5
+    for m in ("forward", "backward"):
+        f = A.IF(mode=None, method=m)
+        back = f.invert(f(X))
+        assert float((back - u).abs().max()) <= 2e-6 * float(u.abs().max()) + 1e-4, m
+        d = getattr(M, "fdiff_" + m)(u)
+        assert float((getattr(M, "fint_" + m)(d) - u).abs().max()) <= 2e-6 * float(u.abs().max()) + 1e-4
+    del u, ang, back, d
+    pol = A.Polar(magnitude_args={"mode": None, "contrast": None, "mel": False}, phase_args={"mode": None}).to(dev)
+    Y = pol(X)
+    assert Y.shape == (B, T, 2, F)
+    Xr = pol.invert(Y)
+    assert float((Xr - X).abs().max()) < 1e-5 * float(X.abs().max())

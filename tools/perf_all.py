@@ -55,6 +55,19 @@ if "fused" in which or "fused2" in which:
 if "fusedraw" in which:
     mgr = A.Magnitude(n_mels=128, mode=None, contrast=None).to(dev)
     report("fwd+mel raw", timeit(lambda: mgr.forward_fused(m, x, return_spectrum=True)), 5640)
+if "phase" in which:
+    from acids_transforms_amd import ops
+    F = 513
+    report("angle (Phase)", timeit(lambda: ops.phase_scan(X, "angle")), 12 * F)
+    report("unwrap", timeit(lambda: ops.phase_scan(X, "unwrap")), 12 * F)
+    for meth in ("forward", "backward", "central"):
+        report("IF " + meth, timeit(lambda: ops.phase_scan(X, meth)), 12 * F)
+    y = ops.phase_scan(X, "forward")
+    for meth in ("forward", "backward", "central"):
+        report("IF.invert " + meth, timeit(lambda: ops.phase_integrate(y, meth)), 8 * F)
+    mg_ = X.abs()
+    report("polar->complex", timeit(lambda: ops.polar_to_complex(mg_, y)), 16 * F)
+    del y, mg_
 if "polar" in which:
     mag, ph = X.abs(), X.angle()
     report("istft_polar", timeit(lambda: m._istft(mag=mag, phase=ph)), 5128)
