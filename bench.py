@@ -314,7 +314,41 @@ def main():
             del sess
         return rtres
 
+    def extra_phase_repr():
+        # the stft+polar chain's phase side at the same size; HBM-bound scans along time
+        from acids_transforms_amd import ops as _ops
+        Xs = stft(x)
+        res = {}
+
+        def timed(fn, n=5):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+
+        def entry(ms, bytes_per_bin):
+            a = frames_per_step * F_BINS * bytes_per_bin / (ms * 1e-3) / 1e9
+            return {"ms": round(ms, 4), "achieved_GBps": round(a, 1), "frac_of_8TBps": round(a / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes_per_bin": bytes_per_bin}
+
+        res["phase_angle"] = entry(timed(lambda: _ops.phase_scan(Xs, "angle")), 12)
+        res["if_forward"] = entry(timed(lambda: _ops.phase_scan(Xs, "forward")), 12)
+        inst = _ops.phase_scan(Xs, "forward")
+        res["if_invert_forward"] = entry(timed(lambda: _ops.phase_integrate(inst, "forward")), 8)
+        res["if_invert_central"] = entry(timed(lambda: _ops.phase_integrate(inst, "central")), 8)
+        mg_ = Xs.abs()
+        res["polar_to_complex"] = entry(timed(lambda: _ops.polar_to_complex(mg_, inst)), 16)
+        res["note"] = "angle+unwrap+finite difference(+Normalize) fused, one thread per (clip, bin) column"
+        return res
+
     if not args.no_extras:
+        if rank == 0:
+            guarded("phase_representations", extra_phase_repr)
         if world > 1 and not rehearsal:
             guarded("with_feature_allgather_frames_per_s", extra_allgather)
         if rank == 0 and args.pghi_clips > 0:

@@ -58,6 +58,7 @@ if "fusedraw" in which:
 if "phase" in which:
     from acids_transforms_amd import ops
     F = 513
+    report("angle elementwise", timeit(lambda: ops.angle(X)), 12 * F)
     report("angle (Phase)", timeit(lambda: ops.phase_scan(X, "angle")), 12 * F)
     report("unwrap", timeit(lambda: ops.phase_scan(X, "unwrap")), 12 * F)
     for meth in ("forward", "backward", "central"):
