@@ -9,8 +9,9 @@ from .mel import MFCC
 from .oadd import OverlapAdd
 from .raw import MuLaw
 from .misc import OneHot
+from .channels import Mono, Stereo, MidSide, Window, Squeeze, Unsqueeze, Transpose
 
 __all__ = ["AudioTransform", "ComposeAudioTransform", "NotInvertibleError", "InversionEnumType",
            "apply_transform_to_list", "apply_invert_transform_to_list", "STFT", "RealtimeSTFT", "DGT", "RealtimeDGT",
            "Normalize", "Magnitude", "Real", "Imaginary", "Phase", "IF", "SpectralRepresentation", "Cartesian", "Polar",
-           "PolarIF", "MFCC", "OverlapAdd", "MuLaw", "OneHot"]
+           "PolarIF", "MFCC", "OverlapAdd", "MuLaw", "OneHot", "Mono", "Stereo", "MidSide", "Window", "Squeeze", "Unsqueeze", "Transpose"]

@@ -1,0 +1,260 @@
+"""Channel / layout stage in front of the spectral path: Mono, Stereo, MidSide, Window, and the shape
+helpers Squeeze, Unsqueeze, Transpose (reference transforms/raw.py:11-262, transforms/misc.py:8-152).
+
+These are tensor-layout transforms (select / concatenate / average two channels, strided framing): no kernels
+of their own -- they hand views or small elementwise results to the HIP stages that follow, on whatever
+device the input lives.  Semantics follow the reference, including:
+  * `Mono.invert` looks at the module's own `inversion_mode`, not at the argument (raw.py:70-71);
+  * `MidSide` scales the mid signal by 1/sqrt(2) when `pad_mid` (raw.py:157-158) and its `invert` of a
+    single channel just duplicates it;
+  * `Window.invert` ("crop") keeps the first `hop` samples of every chunk plus the tail of the last one.
+"""
+import math
+from typing import List, Union
+
+import torch
+
+from ..utils.misc import frame
+from .base import AudioTransform, InversionEnumType, NotInvertibleError
+
+__all__ = ["Mono", "Stereo", "MidSide", "Window", "Squeeze", "Unsqueeze", "Transpose"]
+
+
+class Mono(AudioTransform):
+    scriptable = False
+    invertible = True
+    needs_scaling = False
+
+    def __init__(self, mode: str = "mix", normalize: bool = False, squeeze: bool = True, inversion_mode="mono"):
+        super().__init__()
+        self.mode = mode
+        self.squeeze = squeeze
+        self.normalize = normalize
+        self.inversion_mode = inversion_mode
+
+    def __repr__(self):
+        return "Mono(mode=%s, normalize=%s squeeze=%s, inversion_mode=%s)" % (self.mode, self.normalize, self.squeeze,
+                                                                             self.inversion_mode)
+
+    def forward(self, x: Union[torch.Tensor, List[torch.Tensor]]):
+        if isinstance(x, list):
+            return [self(item) for item in x]
+        if x.shape[-2] == 2:
+            if self.mode == "mix":
+                x = (x.sum(-2) / 2).unsqueeze(-2)
+            elif self.mode == "right":
+                x = x[..., 1:2, :]
+            elif self.mode == "left":
+                x = x[..., 0:1, :]
+        if self.normalize:
+            x = x / x.max()
+        if self.squeeze:
+            x = x.squeeze(-2)
+        return x
+
+    def forward_with_time(self, x: torch.Tensor, time: torch.Tensor):
+        time = time[..., 0] if self.squeeze else time[..., 0].unsqueeze(-1)
+        return self(x), time
+
+    def get_inversion_modes(self):
+        return ["mono", "stereo"]
+
+    def invert(self, x, inversion_mode: InversionEnumType = None, tolerance: float = 0.0):
+        if self.squeeze:
+            x = x.unsqueeze(-2)
+        if x.shape[-2] == 1 and self.inversion_mode == "stereo":
+            x = torch.cat([x, x], dim=-2)
+        return x
+
+    def test_inversion(self, x: torch.Tensor):
+        y = self.forward(x)
+        return {mode: self.invert(y, inversion_mode=mode) for mode in self.get_inversion_modes()}
+
+
+def _two_channels(x: torch.Tensor, second) -> torch.Tensor:
+    """1-D -> (2, n); (..., 1, n) -> (..., 2, n) with `second(x)` as the other channel."""
+    if x.ndim == 1:
+        return torch.stack([x, second(x)], dim=0)
+    return torch.cat([x, second(x)], dim=-2)
+
+
+class Stereo(AudioTransform):
+    scriptable = False
+    invertible = True
+    needs_scaling = False
+
+    def __init__(self, normalize=False, sr=44100):
+        super().__init__()
+        self.normalize = normalize
+
+    def __repr__(self):
+        return "Stereo(normalize=%s)" % self.normalize
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1 or x.shape[-2] == 1:
+            x = _two_channels(x, lambda t: t)
+        elif x.shape[-2] > 2:
+            raise Exception("Stereo only works with 1/2 channels")
+        if self.normalize:
+            x = x / x.max()
+        return x
+
+    def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        if x.ndim == 1 or x.shape[-2] == 1:
+            return _two_channels(x, lambda t: t)
+        if x.shape[-2] > 2:
+            return x[..., :2, :]
+        return x
+
+
+class MidSide(AudioTransform):
+    scriptable = False
+    invertible = True
+    needs_scaling = False
+
+    def __init__(self, sr=44100, normalize=False, pad_mid=True):
+        super().__init__(sr=sr)
+        self.pad_mid = pad_mid
+        self.normalize = normalize
+
+    def __repr__(self):
+        return "MidSide(normalize=%s)" % self.normalize
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 1 or x.shape[-2] == 1:
+            x = _two_channels(x, torch.zeros_like)          # mono: the side channel is silence
+        elif x.shape[-2] > 2:
+            raise Exception("MidSide only works with 1 or 2 channels")
+        else:
+            left, right = x[..., 0, :], x[..., 1, :]
+            mid = (left + right) / 2
+            side = (left - right) / 2
+            if self.pad_mid:
+                mid = mid / math.sqrt(2)
+            x = torch.stack([mid, side], -2)
+        if self.normalize:
+            x = x / x.max()
+        return x
+
+    def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        if x.ndim == 1 or x.shape[-2] == 1:
+            return _two_channels(x, lambda t: t)
+        x = x[..., :2, :]
+        mid, side = x[..., 0, :], x[..., 1, :]
+        if self.pad_mid:
+            mid = mid * math.sqrt(2)
+        return torch.stack([mid + side, mid - side], dim=-2)
+
+
+class Window(AudioTransform):
+    scriptable = False
+    invertible = True
+    needs_scaling = False
+
+    def __init__(self, sr: int = 44100, window_size: int = 1024, hop_size: int = 256, dim: int = -1, batch_dim: int = 0,
+                 inversion_mode: str = "crop"):
+        super().__init__()
+        self.sr = sr
+        self.window_size = window_size
+        self.hop_size = hop_size or self.window_size
+        assert self.window_size >= self.hop_size
+        self.dim = dim
+        self.batch_dim = batch_dim
+        self.inversion_mode = inversion_mode
+
+    def __repr__(self):
+        return "Window(ws=%s, hs=%s, dim=%s, inversion=%s)" % (self.window_size, self.hop_size, self.dim, self.inversion_mode)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return frame(x, self.window_size, self.hop_size, self.dim)
+
+    @property
+    def ratio(self):
+        return self.hop_size
+
+    def forward_with_time(self, x: torch.Tensor, time: torch.Tensor):
+        chunks = self.forward(x)
+        n_chunks = chunks.size(-2)
+        shifts = (torch.arange(n_chunks) * self.hop_size / self.sr).to(time.device)
+        return chunks, shifts.expand(tuple(chunks.shape[:-2]) + (n_chunks,)) + time.unsqueeze(-1)
+
+    def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        dim = self.dim if self.dim >= 0 else x.ndim + self.dim
+        if self.window_size == self.hop_size:                  # no overlap: chunks are simply laid end to end
+            shape = list(x.shape)
+            return x.reshape(shape[:dim - 1] + [shape[dim - 1] * shape[dim]] + shape[dim + 1:])
+        if self.inversion_mode == "crop":
+            heads = x.narrow(dim, 0, self.hop_size)             # first hop of every chunk ...
+            n = x.size(dim - 1)
+            shape = list(heads.shape)
+            body = heads.reshape(shape[:dim - 1] + [n * self.hop_size] + shape[dim + 1:])
+            tail = x.select(dim - 1, n - 1).narrow(dim - 1, self.hop_size, x.size(dim) - self.hop_size)
+            return torch.cat([body, tail], dim - 1)             # ... plus the rest of the last one
+        return x
+
+
+class Unsqueeze(AudioTransform):
+    scriptable = False
+    needs_scaling = False
+
+    @property
+    def invertible(self):
+        return self.dim is not None
+
+    def __repr__(self):
+        return "Unsqueeze(dim=%s)" % self.dim
+
+    def __init__(self, sr=44100, dim=1):
+        super().__init__(sr)
+        self.dim = dim
+
+    def forward(self, x: torch.Tensor):
+        return x.unsqueeze(self.dim)
+
+    def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        return x.squeeze(self.dim)
+
+
+class Squeeze(AudioTransform):
+    scriptable = False
+    needs_scaling = False
+
+    @property
+    def invertible(self):
+        return self.dim is not None
+
+    def __init__(self, sr=44100, dim=None):
+        super().__init__(sr)
+        self.dim = dim
+
+    def __repr__(self):
+        return "Squeeze(dim=%s)" % self.dim
+
+    def forward(self, x: torch.Tensor):
+        return x.squeeze() if self.dim is None else x.squeeze(self.dim)
+
+    def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        if self.dim is None:
+            raise NotInvertibleError
+        return x.unsqueeze(self.dim)
+
+
+class Transpose(AudioTransform):
+    scriptable = False
+    invertible = True
+    needs_scaling = False
+
+    def __repr__(self):
+        return "Transpose(dims=%s, contiguous=%s)" % (self.dims, self.contiguous)
+
+    def __init__(self, dims=(-2, -1), contiguous=True):
+        super().__init__()
+        self.dims = list(dims)
+        self.contiguous = bool(contiguous)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = x.transpose(self.dims[0], self.dims[1])
+        return y.contiguous() if self.contiguous else y
+
+    def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4):
+        return self(x)

@@ -528,9 +528,52 @@ def g11():
     save("g11_phase_repr", **out)
 
 
+
+# --------------------------------------------------------------------------
+# G12: channel / layout stage (Mono, Stereo, MidSide, Window, Squeeze, Unsqueeze, Transpose)
+# --------------------------------------------------------------------------
+def g12():
+    out = {}
+    st = sig_noise((3, 2, 100), 120)
+    mo = sig_noise((3, 1, 100), 121)
+    one = sig_noise((50,), 122)
+    out.update(st=st, mo=mo, one=one)
+    for mode in ("mix", "left", "right"):
+        for squeeze in (True, False):
+            for inv in ("mono", "stereo"):
+                m = at.Mono(mode=mode, squeeze=squeeze, inversion_mode=inv, normalize=(mode == "left"))
+                key = "mono_%s_%d_%s" % (mode, int(squeeze), inv)
+                y = m(st)
+                out[key] = y
+                out[key + "_inv"] = m.invert(y)
+                out[key + "_m"] = m(mo)
+    y, tm = at.Mono().forward_with_time(st, torch.arange(6.).reshape(3, 2))
+    out["mono_time"] = tm
+    for name, t in (("stereo", at.Stereo()), ("stereo_n", at.Stereo(normalize=True)), ("midside", at.MidSide()),
+                    ("midside_np", at.MidSide(pad_mid=False, normalize=True))):
+        for tag, x in (("st", st), ("mo", mo), ("one", one)):
+            y = t(x)
+            out["%s_%s" % (name, tag)] = y
+            out["%s_%s_inv" % (name, tag)] = t.invert(y)
+    out["stereo_inv3"] = at.Stereo().invert(sig_noise((2, 3, 10), 123))
+    for ws, hs in ((16, 4), (8, 8), (10, 5)):
+        w = at.Window(window_size=ws, hop_size=hs)
+        y = w(st)
+        key = "window_%d_%d" % (ws, hs)
+        out[key] = y
+        out[key + "_inv"] = w.invert(y)
+        _, tm = w.forward_with_time(st, torch.arange(6.).reshape(3, 2))
+        out[key + "_time"] = tm
+    out["squeeze"] = at.Squeeze()(torch.zeros(2, 1, 5, 1))
+    out["squeeze1"] = at.Squeeze(dim=1)(torch.zeros(2, 1, 5, 1))
+    out["unsqueeze"] = at.Unsqueeze()(torch.zeros(2, 5))
+    out["transpose"] = at.Transpose()(st)
+    save("g12_channels", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11"]
-    table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11}
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12"]
+    table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12}
     for w in which:
         print("==", w)
         table[w]()

@@ -184,3 +184,40 @@ def test_full_size_round_trip_properties(dev):
     assert Y.shape == (B, T, 2, F)
     Xr = pol.invert(Y)
     assert float((Xr - X).abs().max()) < 1e-5 * float(X.abs().max())
+
+
+def test_reference_combination_chains(dev):
+    """The four chains of the reference's own combination test (test/test_transforms.py:72-78) run through
+    ComposeAudioTransform exactly as that test drives them: realtime(), scale_data, forward_with_time, invert."""
+    gen = torch.Generator().manual_seed(21)
+    raw = (torch.randn(2, 2, 8192, generator=gen) * 0.3).clamp(-0.99, 0.99).to(dev)    # audio range: codes stay < 256
+    chains = {
+        "stft+magnitude": A.STFT() + A.Magnitude(),
+        "stereo+mulaw+onehot": A.Stereo() + A.MuLaw(channels=256) + A.OneHot(n_classes=256),
+        "stft+polar": A.STFT() + A.Polar(),
+        "overlap+stft": A.OverlapAdd() + A.RealtimeSTFT(),
+    }
+    for name, t in chains.items():
+        t = t.to(dev)
+        t.realtime()
+        if t.needs_scaling:
+            t.scale_data(raw)
+        time = torch.zeros(*raw.shape[:-1], device=dev)
+        y, tm = t.forward_with_time(raw, time)
+        x_inv = t.invert(y)
+        assert torch.isfinite(torch.view_as_real(x_inv) if x_inv.is_complex() else x_inv.float()).all(), name
+        if name == "stft+polar":
+            assert y.shape == (2, 2, 33, 2, 513)
+            X = A.STFT().to(dev)(raw)
+            pol = t[1]
+            assert rel_max(cpu(pol(X)).numpy(), cpu(y).numpy()) < TOL
+            # Polar.invert rebuilds the complex spectrum, STFT.invert the audio: round trip within fp32 noise
+            # of the 513x513 mel / inverse-mel pair being only approximately inverse -> compare phases instead
+            ph = pol.phase.invert(y.select(-2, 1))
+            assert rel_max(cpu(torch.cos(ph)).numpy(), cpu(torch.cos(X.angle())).numpy()) < 1e-4
+            assert x_inv.shape[-1] == 8192
+        if name == "stereo+mulaw+onehot":
+            assert y.shape == (2, 2, 8192, 256) and x_inv.shape == raw.shape
+            assert float((x_inv - raw).abs().max()) < 0.05            # 8-bit companding error
+        if name == "overlap+stft":
+            assert y.shape[-1] == 513 and x_inv.shape[:-1] == raw.shape[:-1]
