@@ -34,6 +34,9 @@ _SIGNATURES = {
     "at_phase_scan": [c_f, c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_f],
     "at_phase_integrate": [c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_polar_to_complex": [c_f, c_f, c_i64, c_f, c_f],
+    "at_sinebank_workspace_bytes": [c_i64, c_int, c_i64, c_int],
+    "at_sinebank_offline": [c_f, c_i64, c_i64, c_int, c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_sz, c_f],
+    "at_sinebank_realtime": [c_f, c_i64, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f],
     "at_mel_project": [c_f, c_int, c_i64, c_i64, c_int, c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_flt, c_f, c_i64,
                        c_i64, c_f],
     "at_mag_pointwise": [c_f, c_int, c_i64, c_int, c_int, c_f, c_f, c_flt, c_f, c_f],
@@ -57,7 +60,8 @@ _SIGNATURES = {
     "at_argmax_last": [c_f, c_f, c_i64, c_int, c_f, c_f],
 }
 _RESTYPES = {"at_error_string": ctypes.c_char_p, "at_istft_workspace_bytes": c_sz, "at_stats_workspace_bytes": c_sz,
-             "at_pghi_offline_workspace_bytes": c_sz, "at_pghi_rt_workspace_bytes": c_sz}
+             "at_pghi_offline_workspace_bytes": c_sz, "at_pghi_rt_workspace_bytes": c_sz,
+             "at_sinebank_workspace_bytes": c_sz}
 
 
 class AcidsHipError(RuntimeError):

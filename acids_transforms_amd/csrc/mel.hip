@@ -21,28 +21,11 @@
 #include <stdint.h>
 
 #include "../../include/acids_hip.h"
+#include "mel_gemm.h"
 
 namespace at_hip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-enum { A_COMPLEX_ABS = 0, A_COMPLEX_ABS2 = 1, A_REAL = 2, A_REAL_ABS = 3 };
-enum { C_NONE = 0, C_LOG1P = 1, C_LOG = 2, C_LOG10 = 3 };
-
-struct MelParams {
-  const void* A;       // rows x K  (complex64 or float32), row stride lda elements
-  const float* Bm;     // K x N row-major, row stride ldb
-  float* out;
-  const float* offset; // device scalars (may be null => no normalisation)
-  const float* scale;
-  long long rows, lda, ld_out;
-  long long T;         // >0: channel-major store out[(r/T)*N*T + n*T + r%T]  (MFCC layout)
-  int K, N, ldb;
-  int a_kind, contrast, inverse;  // inverse: prologue (x*scale+offset, invert_contrast) on A instead of epilogue
-  float eps;
-  int rs;              // LDS row stride in floats
-  long long tiles_per_block;
-};
 
 constexpr int ROWS = 32;
 constexpr int THREADS = 512;
@@ -66,9 +49,10 @@ __device__ __forceinline__ float contrast_inv(float v, int mode, float eps) {
 }
 
 // raw element of A as loaded from HBM (complex pair, or a real value in .x)
-__device__ __forceinline__ float2 load_raw(const MelParams& p, long long row, int k) {
-  if (p.a_kind >= A_REAL) return make_float2(reinterpret_cast<const float*>(p.A)[row * p.lda + k], 0.f);
-  return reinterpret_cast<const float2*>(p.A)[row * p.lda + k];
+__device__ __forceinline__ float2 load_raw(const MelParams& p, long long row, int k, int colblock) {
+  const long long at = row * p.lda + k + (p.a_block_offset ? p.a_block_offset[colblock] : 0);
+  if (p.a_kind >= A_REAL) return make_float2(reinterpret_cast<const float*>(p.A)[at], 0.f);
+  return reinterpret_cast<const float2*>(p.A)[at];
 }
 
 // what the contraction consumes: |.|, |.|^2, or the (de-normalised, de-contrasted) real value
@@ -86,8 +70,8 @@ __device__ __forceinline__ float finish_a(const MelParams& p, float2 c, float of
   return (p.a_kind == A_COMPLEX_ABS2) ? s2 : __builtin_amdgcn_sqrtf(s2);  // |x| (overflow-safe hypot is not needed at audio scale)
 }
 
-__device__ __forceinline__ float load_a(const MelParams& p, long long row, int k, float off, float sc) {
-  return finish_a(p, load_raw(p, row, k), off, sc);
+__device__ __forceinline__ float load_a(const MelParams& p, long long row, int k, int colblock, float off, float sc) {
+  return finish_a(p, load_raw(p, row, k, colblock), off, sc);
 }
 
 // stage rows [4c, 4c+4) x all K of tile `tile` (piece c): issue the global loads only
@@ -102,7 +86,7 @@ __device__ __forceinline__ void piece_load(const MelParams& p, long long tile, i
     const int k = kseg + 128 * i;
     // all but the last 128-column segment are always inside K (NL = ceil(K/128))
     const bool ok = row_ok && (i + 1 < NL || k < p.K);
-    regs[i] = ok ? load_raw(p, row, k) : make_float2(0.f, 0.f);
+    regs[i] = ok ? load_raw(p, row, k, blockIdx.y) : make_float2(0.f, 0.f);
   }
 }
 
@@ -280,7 +264,7 @@ __global__ void mel_gemm_simple_kernel(MelParams p) {
     const long long row = i / p.N;
     const int col = (int)(i - row * p.N);
     float acc = 0.f;
-    for (int k = 0; k < p.K; ++k) acc = fmaf(load_a(p, row, k, off, sc), p.Bm[(long long)k * p.ldb + col], acc);
+    for (int k = 0; k < p.K; ++k) acc = fmaf(load_a(p, row, k, col >> 7, off, sc), p.Bm[(long long)k * p.ldb + col], acc);
     if (!p.inverse) {
       acc = contrast_fwd(acc, p.contrast, p.eps);
       if (p.offset) acc = (acc - off) / sc;
@@ -359,30 +343,14 @@ static int launch_mel(const MelParams& p0, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
-}  // namespace at_hip
-
-using namespace at_hip;
-
-extern "C" {
-
-int at_mel_project(const void* A, int a_kind, int64_t rows, int64_t lda, int K, const float* bank, int ldb, int N,
-                   int contrast, int inverse, const float* offset, const float* scale, float eps, float* out,
-                   int64_t ld_out, int64_t T_transposed, void* stream) {
-  if (rows < 0 || K <= 0 || N <= 0) return AT_EINVAL;
-  if (rows == 0) return AT_OK;
-  if (!A || !bank || !out) return AT_EINVAL;
-  if (a_kind < 0 || a_kind > 3 || contrast < 0 || contrast > 3) return AT_EINVAL;
-  if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
-  if (inverse && a_kind != A_REAL) return AT_EINVAL;
-  MelParams p;
-  p.A = A; p.Bm = bank; p.out = out; p.offset = offset; p.scale = scale;
-  p.rows = rows; p.lda = lda; p.ld_out = ld_out; p.T = T_transposed;
-  p.K = K; p.N = N; p.ldb = ldb; p.a_kind = a_kind; p.contrast = contrast; p.inverse = inverse; p.eps = eps;
+int launch_mel_project(const MelParams& p0, hipStream_t s) {
+  MelParams p = p0;
+  const int K = p.K, N = p.N;
+  const long long rows = p.rows;
   // LDS row stride (floats).  hipcc fuses the A-fragment reads of a j-pair into ds_read2_b64, which is
   // serviced in 16-lane groups over 32 banks: consecutive rows must step by 8 B (mod 128 B) => rs = 32q + 2
   p.rs = ((K - 2 + 31) / 32) * 32 + 2;
   p.tiles_per_block = 1;
-  hipStream_t s = (hipStream_t)stream;
   if (K > 576 || K < 16) {
     long long total = rows * (long long)N;
     long long blocks = (total + 255) / 256;
@@ -407,6 +375,29 @@ int at_mel_project(const void* A, int a_kind, int64_t rows, int64_t lda, int K, 
   if (K >= 32) { AT_MEL_CASE(8) }
   { AT_MEL_CASE(4) }
 #undef AT_MEL_CASE
+}
+
+}  // namespace at_hip
+
+using namespace at_hip;
+
+extern "C" {
+
+int at_mel_project(const void* A, int a_kind, int64_t rows, int64_t lda, int K, const float* bank, int ldb, int N,
+                   int contrast, int inverse, const float* offset, const float* scale, float eps, float* out,
+                   int64_t ld_out, int64_t T_transposed, void* stream) {
+  if (rows < 0 || K <= 0 || N <= 0) return AT_EINVAL;
+  if (rows == 0) return AT_OK;
+  if (!A || !bank || !out) return AT_EINVAL;
+  if (a_kind < 0 || a_kind > 3 || contrast < 0 || contrast > 3) return AT_EINVAL;
+  if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
+  if (inverse && a_kind != A_REAL) return AT_EINVAL;
+  MelParams p;
+  p.A = A; p.Bm = bank; p.out = out; p.offset = offset; p.scale = scale;
+  p.rows = rows; p.lda = lda; p.ld_out = ld_out; p.T = T_transposed;
+  p.K = K; p.N = N; p.ldb = ldb; p.a_kind = a_kind; p.contrast = contrast; p.inverse = inverse; p.eps = eps;
+  p.a_block_offset = nullptr;
+  return launch_mel_project(p, (hipStream_t)stream);
 }
 
 int at_mag_pointwise(const void* A, int a_kind, int64_t n, int contrast, int inverse, const float* offset,

@@ -449,3 +449,36 @@ def polar_to_complex(mag, phase):
     out = torch.empty(mag.shape, dtype=torch.complex64, device=mag.device)
     check(lib().at_polar_to_complex(ptr(mag), ptr(phase), mag.numel(), ptr(out), stream_ptr()), "at_polar_to_complex")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# sinebank inversion (sinebank.hip)
+# ----------------------------------------------------------------------------------------------
+def sinebank_offline(x, c, t, phi, block_frame_offset, W3, max_abs, n_pass):
+    """x (B, T, F) magnitudes -> (B, L) oscillator-bank resynthesis before the final max-normalisation.
+    c (F,), t (L,), phi (F,), W3 (n_pass, L) float32 and block_frame_offset (n_pass, ceil(L/128)) int64 on x's
+    device."""
+    require_device(x, c, t, phi, block_frame_offset, W3, max_abs)
+    c, t, phi, W3 = _f32c(c), _f32c(t), _f32c(phi), _f32c(W3)
+    block_frame_offset = block_frame_offset.contiguous()
+    x = _f32c(x)
+    B, T, F = x.shape
+    L = t.numel()
+    out = torch.empty((B, L), dtype=torch.float32, device=x.device)
+    wsb = lib().at_sinebank_workspace_bytes(B, F, L, n_pass)
+    ws = _workspace(wsb, x.device)
+    check(lib().at_sinebank_offline(ptr(x), B, T, F, ptr(c), ptr(t), ptr(phi), L, n_pass, ptr(block_frame_offset), ptr(W3),
+                                    ptr(max_abs), ptr(out), ptr(ws), wsb, stream_ptr()), "at_sinebank_offline")
+    return out
+
+
+def sinebank_realtime(x, c, tau, phi):
+    """x (S, T, F), tau (T, N), phi (S, F) -> (S, T, N) frames."""
+    require_device(x, c, tau, phi)
+    x, c, tau, phi = _f32c(x), _f32c(c), _f32c(tau), _f32c(phi)
+    S, T, F = x.shape
+    N = tau.shape[-1]
+    out = torch.empty((S, T, N), dtype=torch.float32, device=x.device)
+    check(lib().at_sinebank_realtime(ptr(x), S, T, F, N, ptr(c), ptr(tau), ptr(phi), ptr(out), stream_ptr()),
+          "at_sinebank_realtime")
+    return out

@@ -16,7 +16,7 @@ import torch
 from .. import ops
 from ..utils.misc import frame, reshape_batches
 from .base import AudioTransform, InversionEnumType
-from .stft import _NOT_HOT_PATH, MAX_NFFT, RealtimeSTFT, STFT
+from .stft import MAX_NFFT, RealtimeSTFT, STFT
 
 __all__ = ["DGT", "RealtimeDGT"]
 
@@ -79,7 +79,7 @@ class DGT(STFT):
         elif inversion_mode == "griffin_lim":
             return self.griffin_lim(x)
         elif inversion_mode == "sinebank":
-            raise NotImplementedError(_NOT_HOT_PATH % (inversion_mode, ", 'pghi'"))
+            return self.get_sinebank_inversion(x)
         else:
             raise ValueError("inversion mode %s not valid." % self.inversion_mode)
         return self._istft(mag=x, phase=phase)
@@ -177,7 +177,7 @@ class RealtimeDGT(DGT):
         elif inversion_mode == "random":
             phase = torch.pi * 2 * torch.rand_like(x)
         elif inversion_mode == "sinebank":
-            raise NotImplementedError(_NOT_HOT_PATH % (inversion_mode, ", 'pghi'"))
+            return self.get_sinebank_inversion(x)
         else:
             raise ValueError("inversion mode %s not valid." % self.inversion_mode)
         n = self._n_fft
@@ -188,6 +188,11 @@ class RealtimeDGT(DGT):
         frames, self.hgi_mag_buffer, self.hgi_phase_buffer = ops.rt_polar_irfft_update(
             x, phase, self.inv_window[:n], n, self.hgi_mag_buffer)
         return frames
+
+    def get_sinebank_inversion(self, x_fft: torch.Tensor) -> torch.Tensor:
+        """Per-chunk oscillator bank (reference dgt.py:356-371): (..., n, F) -> (..., n, n_fft) frames."""
+        from .sinebank import sinebank_realtime
+        return sinebank_realtime(self, x_fft)
 
     def pghi(self, mag: torch.Tensor, tolerance=None, noise: torch.Tensor = None):
         """Streaming PGHI (reference dgt.py:338-354, 378-466) for (..., n, F) magnitudes using the

@@ -19,9 +19,6 @@ from .base import AudioTransform, InversionEnumType
 __all__ = ["STFT", "RealtimeSTFT"]
 
 MAX_NFFT = 16384
-_NOT_HOT_PATH = ("inversion mode '%s' is outside the accelerated hot path of acids_transforms_amd "
-                 "(SURVEY.md 8f); use 'keep_input', 'random'%s or a complex input")
-
 
 def _as_clip_layout(x: torch.Tensor, n_fft: int):
     """Describe pre-framed input (..., n, n_fft) to the forward kernel without copying.
@@ -255,8 +252,15 @@ class STFT(AudioTransform):
         if inversion_mode == "griffin_lim":
             return self.griffin_lim(x)
         if inversion_mode == "sinebank":
-            raise NotImplementedError(_NOT_HOT_PATH % (inversion_mode, ""))
+            return self.get_sinebank_inversion(x)
         raise ValueError("inversion mode %s not valid." % inversion_mode)
+
+    def get_sinebank_inversion(self, x_fft: torch.Tensor, random_phase: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Oscillator-bank resynthesis (reference stft.py:180-191): one sinusoid per bin at the bin frequency,
+        amplitude = the magnitude track linearly interpolated to the sample rate, random start phases; output
+        length hop*T + n_fft, peak-normalised.  `random_phase` (F, 1) replaces the random draw (added, for tests)."""
+        from .sinebank import sinebank_offline
+        return sinebank_offline(x_fft, self.sr, self._n_fft, self._hop, random_phase)
 
     def griffin_lim(self, x: torch.Tensor, n_iter: int = 30, momentum: float = 0.99,
                     angles0: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -311,6 +315,7 @@ class RealtimeSTFT(STFT):
 
     def reset(self, x=None):
         self.time_index = torch.tensor(0., device=self.window.device)
+        self.__dict__.pop("_time_index_host", None)
 
     def get_batch_size(self, batch_size: int = None):
         return self.batch_size if batch_size is None else batch_size
@@ -354,10 +359,16 @@ class RealtimeSTFT(STFT):
         elif inversion_mode == "random":
             phase = torch.pi * 2 * torch.rand_like(x)
         elif inversion_mode == "sinebank":
-            raise NotImplementedError(_NOT_HOT_PATH % (inversion_mode, ""))
+            return self.get_sinebank_inversion(x)
         else:
             raise ValueError("inversion mode %s not valid." % self.inversion_mode)
         return ops.irfft_frames(None, self.inv_window[:self._n_fft], self._n_fft, mag=x, phase=phase)
+
+    def get_sinebank_inversion(self, x_fft: torch.Tensor) -> torch.Tensor:
+        """Per-chunk oscillator bank with a running clock and per-stream phases (reference stft.py:276-291):
+        (..., n, F) magnitudes -> (..., n, n_fft) frames."""
+        from .sinebank import sinebank_realtime
+        return sinebank_realtime(self, x_fft)
 
     def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
         out = self(frame(x, self._n_fft, self._hop, -1))

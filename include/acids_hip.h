@@ -221,6 +221,25 @@ int at_phase_integrate(const float *y, int64_t B, int64_t T, int64_t F, int meth
 /* mag * exp(i * phase) -> complex64 (SpectralRepresentation.invert, spectral_repr.py:449-451). */
 int at_polar_to_complex(const float *mag, const float *phase, int64_t n, float *out_complex, void *stream);
 
+/* ---- sinebank inversion --------------------------------------------------- */
+/* STFT/DGT.get_sinebank_inversion (stft.py:180-191): y[b, n] = sum_k env[b,k,n] sin(c_k t_n + phi_k), env = linear
+ * interpolation of x / max|x| along time, / 2 pi.  x: (B, T, F) magnitudes; c[F] = fl(2 pi) f_k, t[L], phi[F]: the
+ * reference's own fp32 frequency / time / random-phase vectors (host-computed with the same torch calls).  Per
+ * 128-sample block cb of the output: block_frame_offset[p * nblocks + cb] (int64, elements) = F * (first frame the
+ * block interpolates from + p), clamped to the last frame, p = 0..n_pass-1 (3 for hop >= 128); W[p * L + n] =
+ * weight of that frame for sample n (zero where unused).  max_abs: device scalar max|x|.  out: (B, L), before the
+ * final division by its max.  n_pass exact-fp32 MFMA contractions against one shared oscillator matrix + a
+ * pointwise combine. */
+size_t at_sinebank_workspace_bytes(int64_t B, int F, int64_t L, int n_pass);
+int at_sinebank_offline(const float *x, int64_t B, int64_t T, int F, const float *c, const float *t, const float *phi,
+                        int64_t L, int n_pass, const int64_t *block_frame_offset, const float *W, const float *max_abs,
+                        float *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* RealtimeSTFT/RealtimeDGT.get_sinebank_inversion (stft.py:276-291, dgt.py:356-371):
+ * out[s, t, n] = (1/F) sum_k x[s, t, k] sin(c_k tau[t, n] + phi[s, k]);  x (S, T, F), tau (T, N), phi (S, F), out (S, T, N). */
+int at_sinebank_realtime(const float *x, int64_t S, int T, int F, int N, const float *c, const float *tau,
+                         const float *phi, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

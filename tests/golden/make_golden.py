@@ -571,9 +571,60 @@ def g12():
     save("g12_channels", **out)
 
 
+
+# --------------------------------------------------------------------------
+# G13: sinebank inversion (offline and per-chunk), with the random phases recorded
+# --------------------------------------------------------------------------
+def g13():
+    out = {}
+    g = torch.Generator().manual_seed(130)
+    drawn = []
+    real_rand = torch.rand
+
+    def recording_rand(*a, **k):
+        r = real_rand(*a, **k)
+        drawn.append(r.clone())
+        return r
+
+    mag = torch.rand(2, 9, 65, generator=g) * 3.0
+    out["mag"] = mag
+    torch.rand = recording_rand
+    try:
+        s = at.STFT(n_fft=128, hop_length=32)
+        drawn.clear()
+        out["offline"] = s.get_sinebank_inversion(mag)
+        out["offline_phase"] = 2 * torch.pi * drawn[-1]
+        d = at.DGT(n_fft=128, hop_length=32)
+        drawn.clear()
+        out["offline_via_invert"] = d.invert(mag, inversion_mode="sinebank")
+        out["offline_via_invert_phase"] = 2 * torch.pi * drawn[-1]
+        # default geometry, one clip, a few frames
+        mag1k = torch.rand(1, 5, 513, generator=g)
+        out["mag1k"] = mag1k
+        drawn.clear()
+        out["offline1k"] = at.STFT().get_sinebank_inversion(mag1k)
+        out["offline1k_phase"] = 2 * torch.pi * drawn[-1]
+        # realtime: three chunks in a row (running clock), batched and unbatched
+        chunks = torch.rand(3, 3, 4, 65, generator=g)
+        out["chunks"] = chunks
+        for name, cls in (("rtstft", at.RealtimeSTFT), ("rtdgt", at.RealtimeDGT)):
+            r = cls(n_fft=128, hop_length=32)
+            drawn.clear()
+            ys = [r.get_sinebank_inversion(chunks[i]) for i in range(3)]
+            out[name] = torch.stack(ys)
+            out[name + "_phase"] = r.random_phase
+            out[name + "_time"] = r.time_index
+        r = at.RealtimeSTFT(n_fft=128, hop_length=32)
+        out["rt_unbatched_phase"] = r.random_phase.clone()
+        out["rt_unbatched"] = torch.stack([r.get_sinebank_inversion(chunks[i, 0]) for i in range(2)])
+    finally:
+        torch.rand = real_rand
+    save("g13_sinebank", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12"]
-    table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12}
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13"]
+    table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}
     for w in which:
         print("==", w)
         table[w]()

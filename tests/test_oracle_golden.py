@@ -265,3 +265,25 @@ def test_phase_representations(golden):
     P = t("polar_m2_1")
     assert P.shape == X.shape[:-1] + (2, X.shape[-1])
     assert torch.allclose(t("polar_none_1_a"), P.select(-2, 0)) and torch.allclose(t("polar_none_1_b"), P.select(-2, 1))
+
+
+def test_sinebank(golden):
+    """oracle sinebank (offline + per-chunk) against the reference's outputs with the recorded random phases."""
+    g = golden("g13_sinebank")
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    y = O.sinebank_offline(t("mag"), 44100, 128, 32, t("offline_phase"))
+    assert y.shape == (2, 32 * 9 + 128) and torch.allclose(y, t("offline"), rtol=1e-5, atol=2e-6)
+    y = O.sinebank_offline(t("mag"), 44100, 128, 32, t("offline_via_invert_phase"))
+    assert torch.allclose(y, t("offline_via_invert"), rtol=1e-5, atol=2e-6)
+    y = O.sinebank_offline(t("mag1k"), 44100, 1024, 256, t("offline1k_phase"))
+    assert torch.allclose(y, t("offline1k"), rtol=1e-5, atol=2e-6)
+    for name in ("rtstft", "rtdgt"):
+        now = torch.tensor(0.)
+        for i in range(3):
+            y, now = O.sinebank_realtime(t("chunks")[i], 44100, 128, 32, t(name + "_phase"), now)
+            assert torch.allclose(y, t(name)[i], rtol=1e-5, atol=2e-6), (name, i)
+        assert torch.equal(now, t(name + "_time"))
+    now = torch.tensor(0.)
+    for i in range(2):
+        y, now = O.sinebank_realtime(t("chunks")[i, 0], 44100, 128, 32, t("rt_unbatched_phase"), now)
+        assert torch.allclose(y, t("rt_unbatched")[i], rtol=1e-5, atol=2e-6)

@@ -69,6 +69,19 @@ if "phase" in which:
     mg_ = X.abs()
     report("polar->complex", timeit(lambda: ops.polar_to_complex(mg_, y)), 16 * F)
     del y, mg_
+if "sinebank" in which:
+    mgs = X.abs()
+    ph0 = 2 * torch.pi * torch.rand(513, 1)
+    nb = int(os.environ.get("SINE_B", "1024"))
+    t_ = timeit(lambda: m.get_sinebank_inversion(mgs[:nb], random_phase=ph0), n=3, warm=1)
+    Lout = 256 * T + 1024
+    print("sinebank offline B=%d  %.2f ms  %.1f Mframes/s  %.1f TFLOP/s (3 passes x 2 B F L)  %.1f Gsine-terms/s" % (
+        nb, t_, nb * T / t_ / 1e3, 3 * 2 * nb * 513 * Lout / t_ / 1e9, nb * 513 * Lout / t_ / 1e6), flush=True)
+    rt = A.RealtimeSTFT().to(dev)
+    ch = torch.rand(256, 4, 513, device=dev)
+    t_ = timeit(lambda: rt.get_sinebank_inversion(ch), n=10, warm=2)
+    print("sinebank realtime 256 streams x 4 frames  %.3f ms per chunk  (%.1f Gsines/s)" % (t_, 256 * 4 * 1024 * 513 / t_ / 1e6))
+    del mgs
 if "polar" in which:
     mag, ph = X.abs(), X.angle()
     report("istft_polar", timeit(lambda: m._istft(mag=mag, phase=ph)), 5128)
