@@ -6,7 +6,6 @@ current torch stream.  No arithmetic happens in Python.
 """
 import torch
 
-from . import _lib
 from ._lib import check, lib, ptr, require_device, stream_ptr
 
 

@@ -16,7 +16,7 @@ import torch
 from .. import ops
 from ..utils.misc import frame, reshape_batches
 from .base import AudioTransform, InversionEnumType
-from .stft import MAX_NFFT, RealtimeSTFT, STFT
+from .stft import RealtimeSTFT, STFT
 
 __all__ = ["DGT", "RealtimeDGT"]
 

@@ -1,7 +1,6 @@
 """MuLaw companding to integer codes (reference transforms/raw.py:265-316, which
 wraps torchaudio MuLawEncoding/MuLawDecoding).  Codes are int64 and must match
 bit for bit: see quant.hip."""
-import torch
 
 from .. import ops
 from .base import AudioTransform, InversionEnumType

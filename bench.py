@@ -117,7 +117,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     red_dev = torch.device("cpu") if rehearsal else dev
     import acids_transforms_amd as A
-    from acids_transforms_amd import ops
 
     B = args.batch
     frames_per_step = B * T_FRAMES

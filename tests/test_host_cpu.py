@@ -3,7 +3,6 @@ constants (goldens), the C ABI surface, and the product/oracle separation."""
 import ctypes
 import os
 import re
-import subprocess
 
 import numpy as np
 import pytest

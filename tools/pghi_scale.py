@@ -8,7 +8,6 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import acids_transforms_amd as A
-from acids_transforms_amd import ops
 
 dev = torch.device("cuda:0")
 L, T, F = 176400, 690, 513
