@@ -110,7 +110,9 @@ __device__ __forceinline__ void piece_store(const MelParams& p, int piece, const
 }
 
 // KSTEPS = number of 4-deep MFMA steps (K_main = 4*KSTEPS <= K); NL = ceil(K/128) loads per thread per piece
-template <int KSTEPS, int NL>
+// DENSE: the bank has no all-zero blocks worth testing for (sinebank's oscillator matrix): no per-step mask
+// test, so the MFMA chain of a staged piece is straight-line code and its LDS reads can run ahead
+template <int KSTEPS, int NL, bool DENSE>
 __global__ __launch_bounds__(THREADS) void mel_gemm_kernel(MelParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* buf0 = smem;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(THREADS) void mel_gemm_kernel(MelParams p) {
 #pragma unroll
       for (int jj = 0; jj < CH; ++jj) {
         const int j = c * CH + jj;
-        if (j < KSTEPS / 2 && ((jmask >> j) & 1ull)) {
+        if (j < KSTEPS / 2 && (DENSE || ((jmask >> j) & 1ull))) {
           const float2 a0 = *reinterpret_cast<const float2*>(a0p + 8 * j);
           const float2 a1 = *reinterpret_cast<const float2*>(a1p + 8 * j);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[2 * j], acc0, 0, 0, 0);
@@ -334,7 +336,7 @@ static int launch_mel(const MelParams& p0, hipStream_t stream) {
   p.tiles_per_block = (ntiles + rowblocks - 1) / rowblocks;
   rowblocks = (ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
   const size_t lds = sizeof(float) * 2 * ROWS * (size_t)p.rs + 16;
-  auto kern = mel_gemm_kernel<KSTEPS, NL>;
+  auto kern = p.dense ? mel_gemm_kernel<KSTEPS, NL, true> : mel_gemm_kernel<KSTEPS, NL, false>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AT_ELAUNCH;
@@ -397,6 +399,7 @@ int at_mel_project(const void* A, int a_kind, int64_t rows, int64_t lda, int K, 
   p.rows = rows; p.lda = lda; p.ld_out = ld_out; p.T = T_transposed;
   p.K = K; p.N = N; p.ldb = ldb; p.a_kind = a_kind; p.contrast = contrast; p.inverse = inverse; p.eps = eps;
   p.a_block_offset = nullptr;
+  p.dense = 0;
   return launch_mel_project(p, (hipStream_t)stream);
 }
 

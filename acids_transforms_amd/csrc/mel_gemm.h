@@ -23,6 +23,7 @@ struct MelParams {
   // optional: element offset added to A for each 128-column block (blockIdx.y) -- the sinebank contraction
   // reads a different frame of the (B, T, F) spectrum for every block of output samples
   const long long* a_block_offset;
+  int dense;           // 1: skip the zero-block bookkeeping (bank known to be dense)
 };
 
 

@@ -116,6 +116,7 @@ int at_sinebank_offline(const float* x, int64_t B, int64_t T, int F, const float
     mp.rows = B; mp.lda = T * (int64_t)F; mp.ld_out = L; mp.T = 0;
     mp.K = F; mp.N = (int)L; mp.ldb = (int)L;
     mp.a_kind = A_REAL; mp.contrast = C_NONE; mp.inverse = 0; mp.eps = 0.f;
+    mp.dense = 1;
     mp.a_block_offset = (const long long*)block_frame_offset + (size_t)p * (size_t)((L + 127) / 128);
     const int rc = launch_mel_project(mp, s);
     if (rc != AT_OK) return rc;
