@@ -34,6 +34,7 @@ _SIGNATURES = {
     "at_phase_scan": [c_f, c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_f],
     "at_phase_integrate": [c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_polar_to_complex": [c_f, c_f, c_i64, c_f, c_f],
+    "at_resample_sinc": [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, c_i64, c_f, c_f],
     "at_sinebank_workspace_bytes": [c_i64, c_int, c_i64, c_int],
     "at_sinebank_offline": [c_f, c_i64, c_i64, c_int, c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_sz, c_f],
     "at_sinebank_realtime": [c_f, c_i64, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f],

@@ -481,3 +481,15 @@ def sinebank_realtime(x, c, tau, phi):
     check(lib().at_sinebank_realtime(ptr(x), S, T, F, N, ptr(c), ptr(tau), ptr(phi), ptr(out), stream_ptr()),
           "at_sinebank_realtime")
     return out
+
+
+def resample_sinc(x, orig, new, width, filters):
+    """x (rows, L) -> (rows, ceil(new * L / orig)) through the (new, 2*width + orig) polyphase bank."""
+    require_device(x, filters)
+    x, filters = _f32c(x), _f32c(filters)
+    rows, L = x.shape
+    out_len = -(-new * L // orig)
+    out = torch.empty((rows, out_len), dtype=torch.float32, device=x.device)
+    check(lib().at_resample_sinc(ptr(x), rows, L, orig, new, width, ptr(filters), out_len, ptr(out), stream_ptr()),
+          "at_resample_sinc")
+    return out

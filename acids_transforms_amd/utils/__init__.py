@@ -1,1 +1,2 @@
 from .misc import *  # noqa
+from .audio_io import Resample, resample, import_data, load_wav  # noqa

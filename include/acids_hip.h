@@ -240,6 +240,13 @@ int at_sinebank_offline(const float *x, int64_t B, int64_t T, int F, const float
 int at_sinebank_realtime(const float *x, int64_t S, int T, int F, int N, const float *c, const float *tau,
                          const float *phi, float *out, void *stream);
 
+/* ---- audio front end ------------------------------------------------------------------------------------- */
+/* torchaudio.transforms.Resample(orig, new) with default arguments, as utils/misc.py:31-33 uses it (algorithm
+ * restated, torchaudio is not in the reference tree).  x: (rows, L); orig/new: the rates divided by their gcd;
+ * filters: new x (2*width + orig) float32 polyphase bank; out: (rows, out_len), out_len = ceil(new * L / orig). */
+int at_resample_sinc(const float *x, int64_t rows, int64_t L, int orig, int new_, int width, const float *filters,
+                     int64_t out_len, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
