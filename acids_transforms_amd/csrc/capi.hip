@@ -16,7 +16,7 @@ struct BandBank {
   const int* lane_start;
   const float* weights;
   int n_filters, n_passes;
-  int pass_len[4];
+  int pass_len[16];
 };
 int launch_stft1024_h256_fwd(const float*, long long, long long, long long, long long, const float*, const float2*,
                              float2*, float*, const BandBank*, float*, const float*, const float*, float, int, int, int,
@@ -135,12 +135,12 @@ int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_strid
   if (n_fft != 1024 || hop != 256 || (clip_stride & 1)) return AT_EUNSUPPORTED;
   if (B * T == 0) return AT_OK;
   if (!x || !window || !feat || !lane_filter || !lane_start || !band_weights || !pass_len_host) return AT_EINVAL;
-  if (n_filters <= 0 || n_passes <= 0 || n_passes > 4 || n_filters > 64 * n_passes) return AT_EINVAL;
+  if (n_filters <= 0 || n_passes <= 0 || n_passes > 16 || n_filters > 64 * n_passes) return AT_EINVAL;
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
   if (L <= n_fft / 2 || (((uintptr_t)window) & 7) || (((uintptr_t)band_weights) & 15)) return AT_EINVAL;
   const float2* tw = twiddles_for_current_device();
   if (!tw) return AT_ENOTINIT;
-  BandBank bank = {lane_filter, lane_start, band_weights, n_filters, n_passes, {0, 0, 0, 0}};
+  BandBank bank = {lane_filter, lane_start, band_weights, n_filters, n_passes, {0}};
   long long table_floats = 0;
   for (int q = 0; q < n_passes; ++q) {
     if (pass_len_host[q] < 0 || pass_len_host[q] > 128 || (pass_len_host[q] & 3)) return AT_EINVAL;  // 4 bins per step

@@ -13,6 +13,7 @@
 // registers across a run of frames.  No workgroup barrier anywhere; a
 // 256-thread block is just four independent waves sharing an LDS allocation.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "fft512.h"
@@ -145,12 +146,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stft1024_fwd_kernel(FwdP
 // of 4), four bins per step.  The weights are stored pass-major, step-major, lane-minor -- the float4 of
 // step j sits at float4 index (quad_base[q] + j) * 64 + l -- so a wave's weight read is 1 KB contiguous
 // (conflict-free ds_read_b128); the host picks the lanes so that the magnitude reads do not collide either.
+constexpr int kMaxBandPasses = 16;   // 64 filters per pass: banks of up to 1024 filters (the reference's default is 513)
 struct BandBank {
   const int* lane_filter;
   const int* lane_start;
   const float* weights;
   int n_filters, n_passes;
-  int pass_len[4];   // bins walked in each pass (multiple of 4)
+  int pass_len[kMaxBandPasses];   // bins walked in each pass (multiple of 4)
 };
 constexpr int kMaxBandFloats = 8192;   // LDS copy of the weights (dynamic LDS): 64 * sum(pass_len) floats <= 32 KB
 
@@ -333,9 +335,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
       absrow[576 + lane] = 0.0f;
       wave_lds_sync();
       const float4* w = reinterpret_cast<const float4*>(wlds) + lane;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q >= p.bank.n_passes) break;
+      // one pass: this lane's filter of pass q summed over its band, contrast / normalise, store (or park in
+      // the channel-major register window `cmrow`, a compile-time row of `cm`)
+      auto one_pass = [&](int q, auto cmsel) {
+        constexpr int CMROW = decltype(cmsel)::value;     // -1: no register window
         const int f = lane_tab[(p.bank.n_passes + q) * 64 + lane];
         // one ds_read_b128 of magnitudes and one of weights per four multiply-adds
         const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
@@ -352,32 +355,39 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
         if (f >= 0) {
           acc = fwd_contrast(acc, p.contrast, p.eps);
           if (p.offset) acc = (acc - mel_off) / mel_sc;
-          if (CMBUF) {
-            if (q < CMBUF) {
+          if constexpr (CMROW >= 0) {
 #pragma unroll
-              for (int k = 0; k < 7; ++k) cm[q][k] = cm[q][k + 1];
-              cm[q][7] = acc;
-            }
+            for (int k = 0; k < 7; ++k) cm[CMROW][k] = cm[CMROW][k + 1];
+            cm[CMROW][7] = acc;
           } else if (p.feat_channel_major) {
             p.feat[((long long)b * p.bank.n_filters + f) * p.T + t_cur] = acc;
           } else {
             frow[f] = acc;
           }
         }
-        if (CMBUF && q < CMBUF && ((t_cur & 7) == 7 || t_cur == t1 - 1) && f >= 0) {
-          // frames [first, t_cur] of the window are new since the last flush (or the start of the run)
-          long long first = t_cur & ~7LL;
-          if (first < t0) first = t0;
-          float* dst = p.feat + ((long long)b * p.bank.n_filters + f) * p.T + (t_cur - 7);
-          if (first == t_cur - 7 && !(p.T & 1)) {         // whole group, rows 8-byte aligned
+        if constexpr (CMROW >= 0) {
+          if (((t_cur & 7) == 7 || t_cur == t1 - 1) && f >= 0) {
+            // frames [first, t_cur] of the window are new since the last flush (or the start of the run)
+            long long first = t_cur & ~7LL;
+            if (first < t0) first = t0;
+            float* dst = p.feat + ((long long)b * p.bank.n_filters + f) * p.T + (t_cur - 7);
+            if (first == t_cur - 7 && !(p.T & 1)) {         // whole group, rows 8-byte aligned
 #pragma unroll
-            for (int k = 0; k < 8; k += 2) *reinterpret_cast<float2*>(dst + k) = make_float2(cm[q][k], cm[q][k + 1]);
-          } else {
+              for (int k = 0; k < 8; k += 2)
+                *reinterpret_cast<float2*>(dst + k) = make_float2(cm[CMROW][k], cm[CMROW][k + 1]);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-              if (t_cur - 7 + k >= first) dst[k] = cm[q][k];
+              for (int k = 0; k < 8; ++k)
+                if (t_cur - 7 + k >= first) dst[k] = cm[CMROW][k];
+            }
           }
         }
+      };
+      if constexpr (CMBUF >= 1) {            // the launcher picks CMBUF == n_passes (1 or 2)
+        one_pass(0, std::integral_constant<int, 0>());
+        if constexpr (CMBUF >= 2) one_pass(1, std::integral_constant<int, 1>());
+      } else {
+        for (int q = 0; q < p.bank.n_passes; ++q) one_pass(q, std::integral_constant<int, -1>());
       }
       wave_lds_sync();
       frow += p.bank.n_filters;

@@ -27,7 +27,7 @@ A bank that is not banded enough reports `eligible = False` and the dense MFMA p
 import numpy as np
 import torch
 
-MAX_PASSES = 4        # filters per lane (N <= 256)
+MAX_PASSES = 16       # filters per lane (N <= 1024; the reference's default bank has 513)
 MAX_BAND = 128        # longest band a lane will walk
 MAX_TABLE_FLOATS = 8192   # LDS copy of the weights (kMaxBandFloats in stft1024.hip), dynamic LDS
 # lanes served together by one LDS cycle of a ds_read_b128 (MI355X_MICROARCH.md, LDS table)
@@ -127,7 +127,7 @@ class BandedBank:
             return
         # passes: filters sorted by band length, 64 per pass, so that every pass walks bands of similar length
         order = np.argsort(-n_quads, kind="stable")
-        pass_len = np.zeros(4, np.int32)
+        pass_len = np.zeros(MAX_PASSES, np.int32)
         lane_filter = np.full(self.n_passes * 64, -1, np.int32)
         lane_start = np.zeros(self.n_passes * 64, np.int32)
         tables = []

@@ -57,7 +57,7 @@ int at_stft_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, i
 /* Fused forward for Compose(STFT|DGT -> Magnitude(mel)) and for MFCC (n_fft = 1024, hop = 256):
  * the same framing + rFFT kernel additionally emits normalise(contrast(|X|^p @ bank)) from registers, so
  * the spectrum is not re-read (spectral_repr.py:215-226 / mel.py:43-44,68-73 behind stft.py:98-104).
- * The bank is passed in banded form, as the walk of the kernel's epilogue: in pass q (n_passes <= 4) lane l
+ * The bank is passed in banded form, as the walk of the kernel's epilogue: in pass q (n_passes <= 16) lane l
  * of a wavefront sums filter lane_filter[q*64 + l] (-1: none) over pass_len_host[q] bins starting at bin
  * lane_start[q*64 + l]; both arrays are DEVICE int32[n_passes*64], pass_len_host is a HOST array of
  * multiples of 4 (<= 128), lane_start entries are multiples of 4 with lane_start + pass_len <= 640.

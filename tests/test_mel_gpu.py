@@ -223,17 +223,40 @@ def test_fused_stft_mel_equals_separate_stages(dev):
             big = np.abs(Xn) > 1e-2
             dphi = np.angle(np.exp(1j * (cpu(st.phase_buffer.reshape(10, 36, 513)) - np.angle(Xn))))
             assert np.abs(dphi[big]).max() < 1e-3
-    # not fusable: odd clip length, reference-default 513-filter bank, realtime stage -> plain two-stage path
+    # not fusable: odd clip length, realtime stage, a dense (non-banded) bank -> plain two-stage path
     st, mg = A.STFT().to(dev), A.Magnitude(n_mels=128, mode=None).to(dev)
     assert not mg.can_fuse_with(st, torch.zeros(2, 9001, device=dev))
-    assert not A.Magnitude(mode=None).to(dev).can_fuse_with(st, torch.zeros(2, 9000, device=dev))
     assert not mg.can_fuse_with(A.RealtimeSTFT().to(dev), torch.zeros(2, 9000, device=dev))
+    dense = A.Magnitude(n_mels=32, mode=None)
+    dense._set_bank(torch.rand(513, 32))
+    assert not dense.to(dev).can_fuse_with(st, torch.zeros(2, 9000, device=dev))
     yo = (st + mg)(x[..., :8999].to(dev))
     assert yo.shape == (5, 2, 36, 128)
     # editing the bank buffer invalidates the cached band table
     mg.mel_bank[0, 100, 5] = 0.5
     y_edit = (st + mg)(x.to(dev))
     assert rel_max(cpu(y_edit), cpu(mg(st(x.to(dev))))) < TOL
+
+
+def test_fused_reference_default_chain(dev):
+    """`STFT() + Magnitude()` with every default -- the reference's own "stft+magnitude" chain: a 513-filter
+    bank (109 of them empty), nine passes of the fused epilogue.  Same features as stage by stage and the oracle."""
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(3, 12000, generator=g) * 0.1
+    st, mg = A.STFT().to(dev), A.Magnitude().to(dev)
+    comp = st + mg
+    xd = x.to(dev)
+    comp.scale_data(xd)
+    assert mg.can_fuse_with(st, xd) and mg._banded().n_passes == 9
+    y = comp(xd)
+    y2 = mg(st(xd))
+    assert y.shape == y2.shape == (3, 47, 513)
+    assert rel_max(cpu(y), cpu(y2)) < TOL
+    Xr = O.stft_forward(x, O.hann_window(1024), 1024, 256)
+    fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 513, 44100))
+    off, sc = O.magnitude_scale_stats(Xr, "log1p", "unipolar")
+    assert rel_max(cpu(y), O.magnitude_forward(Xr, fwd, "log1p", off, sc).numpy()) < TOL
+    assert float(y[..., 0].abs().max()) == float(y2[..., 0].abs().max())      # empty filters: contrast(0), normalised
 
 
 def test_fused_random_banded_bank(dev):

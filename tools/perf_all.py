@@ -52,6 +52,10 @@ if "fused" in which or "fused2" in which:
     if "fused2" in which:
         mf = A.MFCC().to(dev)   # features only: the spectrum never reaches HBM
         report("fwd+mel (no X)", timeit(lambda: mf(x)), 1024 + 512)
+if "fused513" in which:
+    mg5 = A.Magnitude().to(dev)            # reference default: 513-filter bank
+    mg5.scale_data(X[:8])
+    report("fwd+mel513 fused", timeit(lambda: mg5.forward_fused(m, x, return_spectrum=True)), 1024 + 4104 + 2052)
 if "fusedraw" in which:
     mgr = A.Magnitude(n_mels=128, mode=None, contrast=None).to(dev)
     report("fwd+mel raw", timeit(lambda: mgr.forward_fused(m, x, return_spectrum=True)), 5640)
