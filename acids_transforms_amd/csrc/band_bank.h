@@ -1,0 +1,22 @@
+// band_bank.h -- the banded filterbank walk shared by the fused STFT epilogue (stft1024.hip) and the stand-alone
+// banded projection (mel_banded.hip).
+#pragma once
+
+namespace at_hip {
+
+// Banded filterbank for the fused |X| -> mel epilogue (host side: utils/banded.py).  In pass q lane l sums
+// filter lane_filter[q*64+l] (-1: none) over pass_len[q] bins starting at bin lane_start[q*64+l] (a multiple
+// of 4), four bins per step.  The weights are stored pass-major, step-major, lane-minor -- the float4 of
+// step j sits at float4 index (quad_base[q] + j) * 64 + l -- so a wave's weight read is 1 KB contiguous
+// (conflict-free ds_read_b128); the host picks the lanes so that the magnitude reads do not collide either.
+constexpr int kMaxBandPasses = 16;   // 64 filters per pass: banks of up to 1024 filters (the reference's default is 513)
+struct BandBank {
+  const int* lane_filter;
+  const int* lane_start;
+  const float* weights;
+  int n_filters, n_passes;
+  int pass_len[kMaxBandPasses];   // bins walked in each pass (multiple of 4)
+};
+constexpr int kMaxBandFloats = 8192;   // LDS copy of the weights (dynamic LDS): 64 * sum(pass_len) floats <= 32 KB
+
+}  // namespace at_hip

@@ -1,0 +1,242 @@
+// mel_banded.hip -- stand-alone projection of a stored spectrum onto a *banded* filterbank, with the same
+// prologue / epilogue options as the dense MFMA projection of mel.hip:
+//     forward  normalise(contrast(|x|^p @ bank))                      spectral_repr.py:215-226, mel.py:68-73
+//     inverse  invert_contrast(y * scale + offset) @ inverse_bank      spectral_repr.py:228-240
+// Mel banks -- the reference's default 513 x 513 one included, and its row-normalised transpose used by
+// `invert` -- are banded: column n is non-zero on a short run of rows only.  A dense contraction spends
+// 2 K N flops per frame on what are ~1000 useful multiply-adds; it is MFMA-bound at 5 ms for 1024 clips where
+// the data could stream through in under 1 ms.  Here one wavefront takes one frame at a time: the K (<= 640)
+// input values go through the prologue into a 2.5 KB LDS row, then every lane walks the band of one filter per
+// pass exactly as the fused STFT epilogue does (band_bank.h, utils/banded.py: conflict-free ds_read_b128 of
+// values and weights), and the epilogue writes N outputs.  HBM-bound: the input row in, N floats out.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/acids_hip.h"
+#include "band_bank.h"
+#include "mel_gemm.h"   // A_* / C_* codes
+
+namespace at_hip {
+
+struct BandedParams {
+  const void* A;        // rows x K (complex64 or float32), contiguous rows of lda elements
+  float* out;
+  const float* offset;  // device scalars (may be null)
+  const float* scale;
+  long long rows, lda, ld_out;
+  long long T;          // > 0: channel-major store out[(r / T) * N * T + n * T + r % T]
+  long long rows_per_wave;
+  BandBank bank;
+  int K, a_kind, contrast, inverse;
+  float eps;
+};
+
+constexpr int kBandedWaves = 8;     // waves per workgroup, sharing the LDS weight table
+constexpr int kRowFloats = 640;     // LDS row: K values + zero padding a walk may run into
+constexpr int kMaxSeg = kRowFloats / 64;   // 64-element segments per row (10)
+
+__device__ __forceinline__ float banded_contrast_fwd(float v, int mode, float eps) {
+  switch (mode) {
+    case C_LOG1P: return logf(1.0f + v);
+    case C_LOG: return logf(fmaxf(v, eps));
+    case C_LOG10: return log10f(fmaxf(v, eps));
+    default: return v;
+  }
+}
+__device__ __forceinline__ float banded_contrast_inv(float v, int mode, float eps) {
+  switch (mode) {
+    case C_LOG1P: return expf(v) - 1.0f;
+    case C_LOG: return expf(v) - eps;
+    case C_LOG10: return powf(10.0f, v);
+    default: return v;
+  }
+}
+
+template <bool CPLX, int NSEG>   // NSEG = ceil(K / 64)
+__global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedParams p) {
+  __shared__ float rows_lds[kBandedWaves * kRowFloats];
+  extern __shared__ float4 band_lds[];   // weight table, then lane_start / lane_filter
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* wlds = reinterpret_cast<float*>(band_lds);
+  int table_floats = 0;
+  for (int q = 0; q < p.bank.n_passes; ++q) table_floats += 64 * p.bank.pass_len[q];
+  for (int i = threadIdx.x; i < table_floats; i += 64 * kBandedWaves) wlds[i] = p.bank.weights[i];
+  int* lane_tab = reinterpret_cast<int*>(wlds + table_floats);
+  for (int i = threadIdx.x; i < 64 * p.bank.n_passes; i += 64 * kBandedWaves) {
+    lane_tab[i] = p.bank.lane_start[i];
+    lane_tab[64 * p.bank.n_passes + i] = p.bank.lane_filter[i];
+  }
+  float* absrow = rows_lds + wave * kRowFloats;
+#pragma unroll
+  for (int m = NSEG; m < kMaxSeg; ++m) absrow[lane + 64 * m] = 0.0f;   // padding behind the K values stays zero
+  __syncthreads();
+
+  float off = 0.f, sc = 1.f;
+  if (p.offset) {
+    off = *p.offset;
+    sc = *p.scale;
+  }
+  const long long w_id = (long long)blockIdx.x * kBandedWaves + wave;
+  long long r = w_id * p.rows_per_wave;
+  long long r_end = r + p.rows_per_wave;
+  if (r_end > p.rows) r_end = p.rows;
+  if (r >= r_end) return;
+
+  using In = typename std::conditional<CPLX, float2, float>::type;
+  const In* A = reinterpret_cast<const In*>(p.A);
+  auto fetch = [&](long long row, In (&v)[NSEG]) {
+    const In* src = A + row * p.lda;
+#pragma unroll
+    for (int m = 0; m < NSEG; ++m) {
+      const int k = lane + 64 * m;
+      In z;
+      if constexpr (CPLX) z = make_float2(0.f, 0.f);
+      else z = 0.f;
+      v[m] = (m + 1 < NSEG || k < p.K) ? src[k] : z;
+    }
+  };
+  In cur[NSEG], nxt[NSEG];
+  fetch(r, cur);
+  for (; r < r_end; ++r) {
+    const bool more = r + 1 < r_end;
+    if (more) fetch(r + 1, nxt);            // next row on its way while this one is walked
+    // prologue into the LDS row
+#pragma unroll
+    for (int m = 0; m < NSEG; ++m) {
+      float v;
+      if constexpr (CPLX) {
+        const float s2 = fmaf(cur[m].x, cur[m].x, cur[m].y * cur[m].y);
+        v = (p.a_kind == A_COMPLEX_ABS2) ? s2 : __builtin_amdgcn_sqrtf(s2);
+      } else {
+        v = cur[m];
+        if (p.a_kind == A_REAL_ABS) v = fabsf(v);
+        if (p.inverse) {
+          if (p.offset) v = __fadd_rn(__fmul_rn(v, sc), off);
+          v = banded_contrast_inv(v, p.contrast, p.eps);
+        }
+      }
+      const int k = lane + 64 * m;
+      absrow[k] = (m + 1 < NSEG || k < p.K) ? v : 0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float4* w = reinterpret_cast<const float4*>(wlds) + lane;
+    for (int q = 0; q < p.bank.n_passes; ++q) {
+      const int f = lane_tab[(p.bank.n_passes + q) * 64 + lane];
+      const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
+      float acc = 0.f;
+      const int quads = p.bank.pass_len[q] >> 2;
+      for (int j = 0; j < quads; ++j) {
+        const float4 av = a[j], wv = w[j * 64];
+        acc = fmaf(av.x, wv.x, acc);
+        acc = fmaf(av.y, wv.y, acc);
+        acc = fmaf(av.z, wv.z, acc);
+        acc = fmaf(av.w, wv.w, acc);
+      }
+      w += quads * 64;
+      if (f >= 0) {
+        if (!p.inverse) {
+          acc = banded_contrast_fwd(acc, p.contrast, p.eps);
+          if (p.offset) acc = (acc - off) / sc;
+        }
+        if (p.T > 0) {
+          const long long b = r / p.T, t = r - b * p.T;
+          p.out[(b * p.bank.n_filters + f) * p.T + t] = acc;
+        } else {
+          p.out[r * p.ld_out + f] = acc;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < NSEG; ++m) cur[m] = nxt[m];
+    }
+  }
+}
+
+template <bool CPLX>
+static int launch_banded(const BandedParams& p0, size_t dyn_lds, hipStream_t s) {
+  BandedParams p = p0;
+  const int nseg = (p.K + 63) / 64;
+  void (*kernel)(BandedParams) = nullptr;
+  switch (nseg) {
+    case 1: kernel = mel_banded_kernel<CPLX, 1>; break;
+    case 2: kernel = mel_banded_kernel<CPLX, 2>; break;
+    case 3: kernel = mel_banded_kernel<CPLX, 3>; break;
+    case 4: kernel = mel_banded_kernel<CPLX, 4>; break;
+    case 5: kernel = mel_banded_kernel<CPLX, 5>; break;
+    case 6: kernel = mel_banded_kernel<CPLX, 6>; break;
+    case 7: kernel = mel_banded_kernel<CPLX, 7>; break;
+    case 8: kernel = mel_banded_kernel<CPLX, 8>; break;
+    case 9: kernel = mel_banded_kernel<CPLX, 9>; break;
+    default: kernel = mel_banded_kernel<CPLX, 10>; break;
+  }
+  // wave slots of this variant (occupancy x CUs), looked up once per (kernel, table size)
+  struct Entry { const void* k; size_t lds; long long slots; };
+  static thread_local Entry cache[16];
+  static thread_local int n_cached = 0;
+  long long slots = 0;
+  for (int i = 0; i < n_cached; ++i)
+    if (cache[i].k == (const void*)kernel && cache[i].lds == dyn_lds) slots = cache[i].slots;
+  if (!slots) {
+    int cus = 256, dev = 0, nb = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * kBandedWaves, dyn_lds) != hipSuccess || nb <= 0) nb = 2;
+    slots = (long long)cus * nb * kBandedWaves;
+    if (n_cached < 16) cache[n_cached++] = {(const void*)kernel, dyn_lds, slots};
+  }
+  // a few whole rounds of resident waves: the table staging of a block is amortised and the tail stays short
+  long long rpw = (p.rows + 4 * slots - 1) / (4 * slots);
+  if (rpw < 8) rpw = 8;
+  p.rows_per_wave = rpw;
+  const long long waves = (p.rows + rpw - 1) / rpw;
+  const long long blocks = (waves + kBandedWaves - 1) / kBandedWaves;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * kBandedWaves), dyn_lds, s, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+}  // namespace at_hip
+
+using namespace at_hip;
+
+extern "C" {
+
+int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, int K, const int32_t* lane_filter,
+                          const int32_t* lane_start, const float* band_weights, int n_filters, int n_passes,
+                          const int32_t* pass_len_host, int contrast, int inverse, const float* offset, const float* scale,
+                          float eps, float* out, int64_t ld_out, int64_t T_transposed, void* stream) {
+  if (rows < 0 || K <= 0 || n_filters <= 0) return AT_EINVAL;
+  if (rows == 0) return AT_OK;
+  if (!A || !out || !lane_filter || !lane_start || !band_weights || !pass_len_host) return AT_EINVAL;
+  if (a_kind < 0 || a_kind > 3 || contrast < 0 || contrast > 3) return AT_EINVAL;
+  if (n_passes <= 0 || n_passes > kMaxBandPasses || n_filters > 64 * n_passes) return AT_EINVAL;
+  if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
+  if (inverse && a_kind != A_REAL) return AT_EINVAL;
+  if (K > kRowFloats || (((uintptr_t)band_weights) & 15)) return AT_EUNSUPPORTED;
+  BandedParams p = {};
+  p.A = A; p.out = out; p.offset = offset; p.scale = scale;
+  p.rows = rows; p.lda = lda; p.ld_out = ld_out; p.T = T_transposed;
+  p.bank.lane_filter = lane_filter; p.bank.lane_start = lane_start; p.bank.weights = band_weights;
+  p.bank.n_filters = n_filters; p.bank.n_passes = n_passes;
+  p.K = K; p.a_kind = a_kind; p.contrast = contrast; p.inverse = inverse; p.eps = eps;
+  size_t table_floats = 0;
+  for (int q = 0; q < n_passes; ++q) {
+    if (pass_len_host[q] < 0 || pass_len_host[q] > 128 || (pass_len_host[q] & 3)) return AT_EINVAL;
+    p.bank.pass_len[q] = pass_len_host[q];
+    table_floats += (size_t)64 * pass_len_host[q];
+  }
+  if (table_floats > (size_t)kMaxBandFloats) return AT_EUNSUPPORTED;
+  const size_t dyn_lds = table_floats * sizeof(float) + (size_t)2 * 64 * n_passes * sizeof(int);
+  hipStream_t s = (hipStream_t)stream;
+  return a_kind >= A_REAL ? launch_banded<false>(p, dyn_lds, s) : launch_banded<true>(p, dyn_lds, s);
+}
+
+}  // extern "C"

@@ -122,13 +122,30 @@ def _prep_in(x):
     return x if x.is_contiguous() else x.contiguous()
 
 
-def mel_forward(x, bank, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1, channel_major_T=0):
+def _project_banded(x, a_kind, band, contrast, inverse, offset, scale, eps, out, N, channel_major_T):
+    lane_filter, lane_start, weights = band.on(x.device)
+    K = x.shape[-1]
+    check(lib().at_mel_project_banded(ptr(x), a_kind, x.numel() // K, K, K, ptr(lane_filter), ptr(lane_start),
+                                      ptr(weights), N, band.n_passes, band.pass_len.ctypes.data,
+                                      contrast_code(contrast), int(inverse), ptr(offset), ptr(scale), eps, ptr(out), N,
+                                      channel_major_T, stream_ptr()), "at_mel_project_banded")
+    return out
+
+
+def mel_forward(x, bank, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1, channel_major_T=0,
+                band=None):
     """normalise(contrast(|x|^power @ bank)); x: (..., K) complex64/float32, bank: (K, N).
-    channel_major_T = T > 0 stores (..., N, T) for x of shape (..., T, K) (MelSpectrogram layout)."""
+    channel_major_T = T > 0 stores (..., N, T) for x of shape (..., T, K) (MelSpectrogram layout).
+    band: utils.banded.BandedBank of `bank` (eligible) -> the HBM-bound banded walk instead of the dense MFMA
+    contraction."""
     require_device(x, bank)
     x = _prep_in(x)
     K, N = bank.shape[-2], bank.shape[-1]
     assert x.shape[-1] == K, "last dim of the input (%d) must match the bank (%d)" % (x.shape[-1], K)
+    if band is not None and band.eligible and K <= 640:
+        shape = (x.shape[:-2] + (N, channel_major_T)) if channel_major_T else (x.shape[:-1] + (N,))
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        return _project_banded(x, _a_kind(x, power), band, contrast, False, offset, scale, eps, out, N, channel_major_T)
     bank2 = bank.reshape(K, N)
     bank2 = bank2 if bank2.is_contiguous() else bank2.contiguous()
     rows = x.numel() // K
@@ -142,12 +159,16 @@ def mel_forward(x, bank, contrast=None, offset=None, scale=None, eps=1.1920929e-
     return out
 
 
-def mel_inverse(y, inv_bank, contrast=None, offset=None, scale=None, eps=1.1920929e-07):
-    """invert_contrast(y*scale+offset) @ inv_bank; y: (..., K) float32, inv_bank: (K, N)."""
+def mel_inverse(y, inv_bank, contrast=None, offset=None, scale=None, eps=1.1920929e-07, band=None):
+    """invert_contrast(y*scale+offset) @ inv_bank; y: (..., K) float32, inv_bank: (K, N).
+    band: BandedBank of `inv_bank` (eligible) -> banded walk."""
     require_device(y, inv_bank)
     y = _prep_in(y)
     K, N = inv_bank.shape[-2], inv_bank.shape[-1]
     assert y.shape[-1] == K
+    if band is not None and band.eligible and K <= 640:
+        out = torch.empty(y.shape[:-1] + (N,), dtype=torch.float32, device=y.device)
+        return _project_banded(y, 2, band, contrast, True, offset, scale, eps, out, N, 0)
     b2 = inv_bank.reshape(K, N)
     b2 = b2 if b2.is_contiguous() else b2.contiguous()
     rows = y.numel() // K

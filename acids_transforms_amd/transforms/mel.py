@@ -103,7 +103,8 @@ class MFCC(AudioTransform):
         if self.norm is not None and self.n_mfcc is None:
             off, sc = self.norm._params(x)
         if self.n_mfcc is None:
-            mel = ops.mel_forward(X, self.fbank, None, off, sc, power=int(self.power), channel_major_T=T)
+            mel = ops.mel_forward(X, self.fbank, None, off, sc, power=int(self.power), channel_major_T=T,
+                                  band=self._band)
             return mel.reshape(batch_shape + mel.shape[-2:])
         # extension: MFCC = DCT-II(10 log10(mel power)); ln -> dB factor is folded into the DCT matrix
         logmel = ops.mel_forward(X, self.fbank, "log", None, None, eps=1e-10, power=int(self.power))   # (B, T, n_mels)

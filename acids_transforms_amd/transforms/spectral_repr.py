@@ -85,18 +85,22 @@ class Magnitude(AudioTransform):
         return None, None
 
     # -- fusion with the preceding STFT / DGT stage ---------------------------------------------
+    def _band_of(self, name):
+        """Banded walk tables of the buffer `name` (mel_bank / inverse_mel_bank), or None when that bank is not
+        banded enough; rebuilt when the buffer changes."""
+        bank = getattr(self, name)
+        key = (bank.data_ptr(), bank._version)
+        cache = self.__dict__.setdefault("_band_cache", {})
+        if name not in cache or cache[name][0] != key:
+            cache[name] = (key, BandedBank(bank))
+        return cache[name][1] if cache[name][1].eligible else None
+
     def _banded(self):
         """Banded form of `mel_bank` for the fused forward kernel (None when the bank is not banded
-        enough, or when this module's options rule the fusion out); rebuilt when the buffer changes."""
+        enough, or when this module's options rule the fusion out)."""
         if not self.mel or not self.keep_nyquist:
             return None
-        bank = self.mel_bank
-        key = (bank.data_ptr(), bank._version)
-        cached = self.__dict__.get("_band_cache")
-        if cached is None or cached[0] != key:
-            cached = (key, BandedBank(bank))
-            self.__dict__["_band_cache"] = cached
-        return cached[1] if cached[1].eligible else None
+        return self._band_of("mel_bank")
 
     def can_fuse_with(self, stage, x: torch.Tensor) -> bool:
         """True when `stage` (an offline STFT/DGT with n_fft=1024, hop=256) followed by this module can run
@@ -140,7 +144,8 @@ class Magnitude(AudioTransform):
         self._follow(x)
         off, sc = self._affine()
         if self.mel:
-            mag = ops.mel_forward(x, self.mel_bank, self.contrast_mode, off, sc, self._eps)
+            mag = ops.mel_forward(x, self.mel_bank, self.contrast_mode, off, sc, self._eps,
+                                  band=self._band_of("mel_bank"))
         else:
             mag = ops.mag_pointwise(x, self.contrast_mode, off, sc, self._eps)
         if not self.keep_nyquist:
@@ -157,7 +162,8 @@ class Magnitude(AudioTransform):
             x = torch.cat([x, torch.zeros(x.shape[:-1] + (1,), device=x.device, dtype=x.dtype)], -1)
             off = sc = None
         if self.mel:
-            return ops.mel_inverse(x, self.inverse_mel_bank, self.contrast_mode, off, sc, self._eps)
+            return ops.mel_inverse(x, self.inverse_mel_bank, self.contrast_mode, off, sc, self._eps,
+                                   band=self._band_of("inverse_mel_bank"))
         return ops.mag_pointwise(x, self.contrast_mode, off, sc, self._eps, inverse=True)
 
     def scale_data(self, x: torch.Tensor) -> None:

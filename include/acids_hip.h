@@ -199,6 +199,15 @@ int at_onehot(const int64_t *x, int64_t n, int classes, int64_t channel_major_in
 /* Tensor.argmax(-1) (misc.py:188-189): first index of the row maximum. */
 int at_argmax_last(const int64_t *x_i64, const float *x_f32, int64_t rows, int cols, int64_t *out, void *stream);
 
+/* The same projection for a BANDED bank (mel banks, the reference's default 513 x 513 one and its inverse
+ * included): the K <= 640 inputs of a frame go through the prologue into LDS and every lane walks the band of
+ * one filter per pass -- the walk tables are those of at_stft_mel_forward (utils/banded.py).  HBM-bound (input
+ * row in, n_filters floats out) where the dense contraction is MFMA-bound.  Arguments as at_mel_project. */
+int at_mel_project_banded(const void *A, int a_kind, int64_t rows, int64_t lda, int K, const int32_t *lane_filter,
+                          const int32_t *lane_start, const float *band_weights, int n_filters, int n_passes,
+                          const int32_t *pass_len_host, int contrast, int inverse, const float *offset,
+                          const float *scale, float eps, float *out, int64_t ld_out, int64_t T_transposed, void *stream);
+
 /* ---- phase-side representations ------------------------------------------ */
 /* Scan along the frame axis of a (B, T, F) spectrum, one of X_complex / phase given (the angle is taken
  * inside), optional per-frame weight frame_window[T] and Normalize affine (device scalars) applied last:

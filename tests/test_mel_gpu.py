@@ -277,3 +277,40 @@ def test_fused_random_banded_bank(dev):
     Xr = O.stft_forward(x, O.hann_window(1024), 1024, 256)
     fwd, _ = O.magnitude_banks(bank)
     assert rel_max(cpu(y), O.magnitude_forward(Xr, fwd, "log1p").numpy()) < TOL
+
+
+def test_banded_projection_equals_dense_contraction(dev):
+    """at_mel_project_banded (what Magnitude.forward / invert run for a banded bank) against the dense MFMA
+    contraction of the same bank and the oracle: forward |x| and |x|^2, every contrast, with and without
+    normalisation, channel-major output; inverse chain; banks of 513 (reference default), 128 and 65 filters."""
+    from acids_transforms_amd import ops
+    from acids_transforms_amd.utils.banded import BandedBank
+    gen = torch.Generator().manual_seed(41)
+    for n_fft, n_mels, rows in [(1024, 513, (3, 50)), (1024, 128, (2, 2, 33)), (128, 65, (5, 17)), (1024, 40, (1, 1))]:
+        F = n_fft // 2 + 1
+        m = A.Magnitude(n_fft=n_fft, n_mels=n_mels).to(dev)
+        X = (torch.randn(*rows, F, generator=gen) * torch.exp(2j * np.pi * torch.rand(*rows, F, generator=gen))).to(torch.complex64)
+        Xd = X.to(dev)
+        fb = BandedBank(m.mel_bank)
+        ib = BandedBank(m.inverse_mel_bank)
+        assert fb.eligible and ib.eligible
+        off = torch.tensor(0.3, device=dev)
+        sc = torch.tensor(1.7, device=dev)
+        for contrast in ("log1p", "log", "log10", None):
+            for (o, s_) in ((None, None), (off, sc)):
+                for power in (1, 2):
+                    dense = ops.mel_forward(Xd, m.mel_bank, contrast, o, s_, m._eps, power=power)
+                    band = ops.mel_forward(Xd, m.mel_bank, contrast, o, s_, m._eps, power=power, band=fb)
+                    assert band.shape == dense.shape
+                    assert rel_max(cpu(band), cpu(dense)) < TOL, (n_mels, contrast, power)
+                y = ops.mel_forward(Xd, m.mel_bank, contrast, o, s_, m._eps, band=fb)
+                inv_d = ops.mel_inverse(y, m.inverse_mel_bank, contrast, o, s_, m._eps)
+                inv_b = ops.mel_inverse(y, m.inverse_mel_bank, contrast, o, s_, m._eps, band=ib)
+                assert rel_max(cpu(inv_b), cpu(inv_d)) < TOL, (n_mels, contrast)
+        T = rows[-1]
+        cm_d = ops.mel_forward(Xd, m.mel_bank, None, None, None, power=2, channel_major_T=T)
+        cm_b = ops.mel_forward(Xd, m.mel_bank, None, None, None, power=2, channel_major_T=T, band=fb)
+        assert cm_b.shape == rows[:-1] + (n_mels, T) and rel_max(cpu(cm_b), cpu(cm_d)) < TOL
+        fwd, inv = O.magnitude_banks(O.melscale_fbanks(F, 0.0, 22050.0, n_mels, 44100))
+        want = O.magnitude_forward(X, fwd, "log1p")
+        assert rel_max(cpu(m.__class__(n_fft=n_fft, n_mels=n_mels, mode=None).to(dev)(Xd)), want.numpy()) < TOL
