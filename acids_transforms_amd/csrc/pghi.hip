@@ -792,6 +792,163 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_lds_kernel(RtParams p) {
   }
 }
 
+// The same frame step with the wave-cooperative heap of the offline kernel (coop_bubble / coop_siftdown), the
+// whole heap in LDS.  A frame pops up to 2F entries from a heap of ~1000: done by one lane that is ~10 dependent
+// LDS round trips down and a few up per pop (~3600 cycles); the cooperative pop resolves five levels per round
+// with one wide LDS gather.  Same binary heap, same sift rules, same pop order.
+__global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
+  extern __shared__ __attribute__((aligned(16))) float rt_smem[];
+  const int s = blockIdx.x;
+  if (s >= p.S) return;
+  const int lane = threadIdx.x;
+  const int F = p.F, R = p.n + 2;
+  const long long n = (long long)R * F;
+  const float* spec = p.spec + (long long)s * n;
+  const float* tgw = p.tgradw + (long long)s * n;
+  const float* fgw = p.fgradw + (long long)s * n;
+  float* phase = p.phase + (long long)s * n;
+  float* srow = rt_smem;       // working copy of spectrogram row f
+  float* hrow = srow + F;      // untouched row f-1 (spectrogram_history, dgt.py:411)
+  float* ph0 = hrow + F;       // phase row f-1
+  float* ph1 = ph0 + F;        // phase row f
+  float* tg0 = ph1 + F;        // padded tgradw rows f-1 and f
+  float* tg1 = tg0 + F;
+  float* fg1 = tg1 + F;        // padded fgradw row f
+  const Heap H = {reinterpret_cast<u64*>(fg1 + F + (F & 1)), nullptr, 0x7fffffff};
+  auto lds_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto ufloat = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+
+  float smax = -1.0f;
+  for (long long i = lane; i < n; i += 64) smax = fmaxf(smax, spec[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+  float abstol = p.tol * smax;  // :400
+  if (abstol < p.eps) abstol = p.eps;
+
+  for (int k = lane; k < F; k += 64) {  // :402-403 rows 0 and 1 of the phase array
+    phase[k] = 0.0f;
+    phase[F + k] = p.prev_phase[(long long)s * F + k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+
+  for (int f = 2; f < R; ++f) {  // :413
+    float max_val = -1.0f;
+    long long max_k = F;
+    for (int k = lane; k < F; k += 64) {
+      const float v = spec[(long long)f * F + k];
+      srow[k] = v;
+      hrow[k] = spec[(long long)(f - 1) * F + k];
+      ph0[k] = phase[(long long)(f - 1) * F + k];
+      ph1[k] = (v > abstol) ? 0.0f : p.noise[(long long)s * p.n * F + (long long)(f - 2) * F + k];  // :404-405
+      tg0[k] = (f - 1 >= 2) ? tgw[(long long)(f - 3) * F + k] : 0.0f;  // :408-410 two-row front padding
+      tg1[k] = tgw[(long long)(f - 2) * F + k];
+      fg1[k] = fgw[(long long)(f - 2) * F + k];
+      if (v > max_val) {
+        max_val = v;
+        max_k = k;
+      }
+    }
+    wave_argmax(max_val, max_k);
+    max_val = ufloat(max_val);
+    lds_sync();
+    if (max_val > abstol) {  // :416-417
+      int hn = 1;
+      if (lane == 0) H.store(0, pack_item(-max_val, F + (int)max_k));   // :427 the seed is NOT marked visited
+      lds_sync();
+      auto push = [&](float key, int idx) {     // heappush (heapq.py:45-48)
+        coop_siftdown(H, hn, pack_item(key, idx), lane);
+        ++hn;
+        lds_sync();
+      };
+      for (int k = 0; k < F; ++k) {  // :428-430
+        const float hv = ufloat(hrow[k]);
+        if (hv > abstol) push(-hv, k);
+      }
+      while (max_val > abstol) {  // :433
+        while (hn > 0) {
+          // heappop (heapq.py:51-59)
+          const u64 last = H.load(hn - 1);
+          hn -= 1;
+          const int idx = uni(item_idx(hn == 0 ? last : H.load(0)));
+          if (hn > 0) {
+            u64 leaf_old = 0;
+            const int leaf = coop_bubble(H, hn, lane, leaf_old);
+            if (leaf == 0 || !(item_key(last) < item_key(leaf_old))) {
+              if (lane == 0) H.store(leaf, last);
+            } else {
+              coop_siftdown(H, leaf, last, lane);
+            }
+            lds_sync();
+          }
+          const bool cur_row = idx >= F;
+          const int k = cur_row ? idx - F : idx;
+          if (!cur_row) {  // :436-443 propagate in time
+            const float sv = ufloat(srow[k]);
+            if (sv > abstol) {
+              if (lane == 0) {
+                ph1[k] = ph0[k] + 0.5f * (tg0[k] + tg1[k]);
+                srow[k] = abstol;
+              }
+              push(-sv, F + k);
+            }
+          } else {  // :444-460 propagate in frequency
+            if (k + 1 < F) {
+              const float sv = ufloat(srow[k + 1]);
+              if (sv > abstol) {
+                if (lane == 0) {
+                  ph1[k + 1] = ph1[k] + 0.5f * (fg1[k] + fg1[k + 1]);
+                  srow[k + 1] = abstol;
+                }
+                push(-sv, F + k + 1);
+              }
+            }
+            if (k - 1 > 0) {  // bin 0 is never reached downward (:453)
+              const float sv = ufloat(srow[k - 1]);
+              if (sv > abstol) {
+                if (lane == 0) {
+                  ph1[k - 1] = ph1[k] - 0.5f * (fg1[k] + fg1[k - 1]);
+                  srow[k - 1] = abstol;
+                }
+                push(-sv, F + k - 1);
+              }
+            }
+          }
+        }
+        // :461-465 reseed inside the frame: first index of the row maximum, lane-parallel
+        float mv = -3.402823466e+38f;
+        long long mk = F;
+        for (int k = lane; k < F; k += 64) {
+          const float v = srow[k];
+          if (v > mv) {
+            mv = v;
+            mk = k;
+          }
+        }
+        wave_argmax(mv, mk);
+        max_val = ufloat(mv);
+        const int mki = uni((int)mk);
+        push(-max_val, F + mki);
+        if (lane == 0) srow[mki] = abstol;
+        lds_sync();
+      }
+    }
+    lds_sync();
+    for (int k = lane; k < F; k += 64) {
+      const float v = ph1[k];
+      phase[(long long)f * F + k] = v;
+      p.phase_out[(long long)s * p.n * F + (long long)(f - 2) * F + k] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    lds_sync();
+  }
+}
+
 // x = mag * exp(i phase): refresh the PGHI history (|x[-2:]|, angle(x[-1]))   dgt.py:325-336
 struct RtUpdParams {
   const float* mag;       // (S, n, F)
@@ -919,7 +1076,11 @@ int at_pghi_realtime(const float* mag_hist, const float* mag, const float* prev_
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pghi_grad_rt_kernel, dim3(grid1d((long long)S * per)), dim3(256), 0, s, p);
   const size_t lds = sizeof(float) * (7 * (size_t)F + 1) + sizeof(HeapItem) * (4 * (size_t)F + 8);
-  if (lds <= 64 * 1024)
+  // ACIDS_PGHI_SERIAL=1 selects the single-lane kernels (debugging aid; identical results)
+  static const bool serial_rt = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
+  if (lds <= 64 * 1024 && !serial_rt)
+    hipLaunchKernelGGL(pghi_hgi_rt_coop_kernel, dim3((unsigned)S), dim3(64), lds, s, p);
+  else if (lds <= 64 * 1024)
     hipLaunchKernelGGL(pghi_hgi_rt_lds_kernel, dim3((unsigned)S), dim3(64), lds, s, p);
   else
     hipLaunchKernelGGL(pghi_hgi_rt_kernel, dim3((unsigned)S), dim3(64), 0, s, p);
