@@ -365,20 +365,23 @@ __device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64& 
     const bool right_wins = is_right ? (valid && !(sib < key)) : (sib_valid && !(key < sib));
     const bool chosen = valid && (is_right ? right_wins : !right_wins);
     const u64 W = __ballot(chosen && lane >= 2);
-    // walk the chosen-child bits from the subtree root (scalar code).  Exactly one of a node's two child
-    // bits is set while children exist; below a leaf every bit is 0, so the walk simply stops advancing.
-    int cur = 1;
-    u64 pathmask = 0;
+    // The chain of bubbled-up nodes below the subtree root: node L belongs to it iff L and every ancestor of
+    // L down to level 1 is its parent's chosen child.  Each lane tests its own <= 5 bits of W (a serial walk
+    // from the root costs five dependent scalar steps per round); below a leaf no bit is set, so the chain
+    // simply ends there.
+    bool on_chain = (lane >= 2) && ((W >> lane) & 1ull);
+    {
+      int a = lane >> 1;
 #pragma unroll
-    for (int s2 = 0; s2 < 5; ++s2) {
-      const int l = cur << 1;
-      const unsigned bits = (unsigned)(W >> l) & 3u;
-      if (bits) {
-        pathmask |= 1ull << cur;
-        cur = l + (int)(bits >> 1);
+      for (int i = 0; i < 4; ++i) {
+        if (a >= 2) on_chain = on_chain && ((W >> a) & 1ull);
+        a >>= 1;
       }
     }
-    const int steps = __builtin_popcountll(pathmask);
+    const u64 chain = __ballot(on_chain);
+    const int steps = __builtin_popcountll(chain);
+    const int cur = steps ? 63 - __builtin_clzll(chain) : 1;          // the final hole of this round
+    const u64 pathmask = steps ? ((chain & ~(1ull << cur)) | 2ull) : 0ull;   // nodes that receive their chosen child
     // every inner lane knows its chosen child from W; the path nodes fetch that child's entry and store it
     const int cl = (2 * lane) & 63;
     const int nx = ((W >> cl) & 1ull) ? cl : cl + 1;
@@ -875,6 +878,13 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
           const u64 last = H.load(hn - 1);
           hn -= 1;
           const int idx = uni(item_idx(hn == 0 ? last : H.load(0)));
+          const bool cur_row = idx >= F;
+          const int k = cur_row ? idx - F : idx;
+          // the magnitudes this pop may propagate to, requested before the heap repair (they come back first:
+          // LDS returns in order) instead of one round trip each afterwards
+          const float s_here = srow[k];
+          const float s_up = srow[k + 1 < F ? k + 1 : k];
+          const float s_dn = srow[k >= 1 ? k - 1 : 0];
           if (hn > 0) {
             u64 leaf_old = 0;
             const int leaf = coop_bubble(H, hn, lane, leaf_old);
@@ -885,10 +895,8 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
             }
             lds_sync();
           }
-          const bool cur_row = idx >= F;
-          const int k = cur_row ? idx - F : idx;
           if (!cur_row) {  // :436-443 propagate in time
-            const float sv = ufloat(srow[k]);
+            const float sv = ufloat(s_here);
             if (sv > abstol) {
               if (lane == 0) {
                 ph1[k] = ph0[k] + 0.5f * (tg0[k] + tg1[k]);
@@ -898,7 +906,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
             }
           } else {  // :444-460 propagate in frequency
             if (k + 1 < F) {
-              const float sv = ufloat(srow[k + 1]);
+              const float sv = ufloat(s_up);
               if (sv > abstol) {
                 if (lane == 0) {
                   ph1[k + 1] = ph1[k] + 0.5f * (fg1[k] + fg1[k + 1]);
@@ -908,7 +916,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
               }
             }
             if (k - 1 > 0) {  // bin 0 is never reached downward (:453)
-              const float sv = ufloat(srow[k - 1]);
+              const float sv = ufloat(s_dn);
               if (sv > abstol) {
                 if (lane == 0) {
                   ph1[k - 1] = ph1[k] - 0.5f * (fg1[k] + fg1[k - 1]);
