@@ -131,6 +131,31 @@ __global__ __launch_bounds__(256) void phase_scan_kernel(ScanParams p) {
   if (MODE == SCAN_IF_CENTRAL && T > 1) emit(T - 1, u_prev);
 }
 
+// Phase(unwrap=False): no recurrence along time, so no column walk -- a flat grid-stride pass (the same bytes
+// move at 4.7-4.9 TB/s this way against 3.6 TB/s for the walk).
+template <bool CPLX>
+__global__ __launch_bounds__(256) void phase_angle_kernel(ScanParams p) {
+  const long long total = p.B * p.T * p.F;
+  float off = 0.f, sc = 1.f;
+  const bool norm = p.offset != nullptr;
+  if (norm) {
+    off = *p.offset;
+    sc = *p.scale;
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float v;
+    if (CPLX) {
+      const float2 z = p.X[i];
+      v = atan2f(z.y, z.x);
+    } else {
+      v = p.phase[i];
+    }
+    if (p.window) v = p.window[(i / p.F) % p.T] * v;
+    if (norm) v = (v - off) / sc;
+    p.out[i] = v;
+  }
+}
+
 // ---- integration (IF.invert) -------------------------------------------------------------------------
 struct IntParams {
   const float* y;        // (B, T, F) instantaneous frequency (normalised when offset/scale are given)
@@ -283,6 +308,13 @@ int at_phase_scan(const float* X_complex, const float* phase, int64_t B, int64_t
   if (mode < SCAN_UNWRAP || mode > SCAN_ANGLE) return AT_EINVAL;
   if (bare && (mode < SCAN_IF_FORWARD || mode > SCAN_IF_CENTRAL || !phase)) return AT_EINVAL;
   ScanParams p = {(const float2*)X_complex, phase, out, B, T, F, frame_window, offset, scale, bare};
+  if (mode == SCAN_ANGLE) {
+    long long blocks = (B * T * F + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (X_complex) hipLaunchKernelGGL(phase_angle_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(phase_angle_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+  }
   const long long cols = B * F;
   const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
   launch_scan(mode, X_complex != nullptr, frame_window != nullptr, offset != nullptr, grid, block, (hipStream_t)stream, p);
