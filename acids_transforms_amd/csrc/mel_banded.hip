@@ -30,6 +30,12 @@ struct BandedParams {
   BandBank bank;
   int K, a_kind, contrast, inverse;
   float eps;
+  // optional second output for complex input: normalise(angle(x)), rows of ld_phase floats (Polar: the stacked
+  // (.., T, 2, F) tensor is written in place -- magnitudes at row offset 0, phases at row offset F)
+  float* phase_out;
+  long long ld_phase;
+  const float* ph_offset;
+  const float* ph_scale;
 };
 
 constexpr int kBandedWaves = 8;     // waves per workgroup, sharing the LDS weight table
@@ -78,6 +84,11 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
     off = *p.offset;
     sc = *p.scale;
   }
+  float ph_off = 0.f, ph_sc = 1.f;
+  if (p.ph_offset) {
+    ph_off = *p.ph_offset;
+    ph_sc = *p.ph_scale;
+  }
   const long long w_id = (long long)blockIdx.x * kBandedWaves + wave;
   long long r = w_id * p.rows_per_wave;
   long long r_end = r + p.rows_per_wave;
@@ -109,6 +120,14 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
       if constexpr (CPLX) {
         const float s2 = fmaf(cur[m].x, cur[m].x, cur[m].y * cur[m].y);
         v = (p.a_kind == A_COMPLEX_ABS2) ? s2 : __builtin_amdgcn_sqrtf(s2);
+        if (p.phase_out) {
+          const int kk = lane + 64 * m;
+          if (m + 1 < NSEG || kk < p.K) {
+            float ph = atan2f(cur[m].y, cur[m].x);
+            if (p.ph_offset) ph = (ph - ph_off) / ph_sc;
+            p.phase_out[r * p.ld_phase + kk] = ph;
+          }
+        }
       } else {
         v = cur[m];
         if (p.a_kind == A_REAL_ABS) v = fabsf(v);
@@ -212,7 +231,8 @@ extern "C" {
 int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, int K, const int32_t* lane_filter,
                           const int32_t* lane_start, const float* band_weights, int n_filters, int n_passes,
                           const int32_t* pass_len_host, int contrast, int inverse, const float* offset, const float* scale,
-                          float eps, float* out, int64_t ld_out, int64_t T_transposed, void* stream) {
+                          float eps, float* out, int64_t ld_out, int64_t T_transposed, float* phase_out, int64_t ld_phase,
+                          const float* phase_offset, const float* phase_scale, void* stream) {
   if (rows < 0 || K <= 0 || n_filters <= 0) return AT_EINVAL;
   if (rows == 0) return AT_OK;
   if (!A || !out || !lane_filter || !lane_start || !band_weights || !pass_len_host) return AT_EINVAL;
@@ -220,6 +240,8 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
   if (n_passes <= 0 || n_passes > kMaxBandPasses || n_filters > 64 * n_passes) return AT_EINVAL;
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
   if (inverse && a_kind != A_REAL) return AT_EINVAL;
+  if (phase_out && a_kind >= A_REAL) return AT_EINVAL;
+  if ((phase_offset == nullptr) != (phase_scale == nullptr)) return AT_EINVAL;
   if (K > kRowFloats || (((uintptr_t)band_weights) & 15)) return AT_EUNSUPPORTED;
   BandedParams p = {};
   p.A = A; p.out = out; p.offset = offset; p.scale = scale;
@@ -227,6 +249,7 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
   p.bank.lane_filter = lane_filter; p.bank.lane_start = lane_start; p.bank.weights = band_weights;
   p.bank.n_filters = n_filters; p.bank.n_passes = n_passes;
   p.K = K; p.a_kind = a_kind; p.contrast = contrast; p.inverse = inverse; p.eps = eps;
+  p.phase_out = phase_out; p.ld_phase = ld_phase; p.ph_offset = phase_offset; p.ph_scale = phase_scale;
   size_t table_floats = 0;
   for (int q = 0; q < n_passes; ++q) {
     if (pass_len_host[q] < 0 || pass_len_host[q] > 128 || (pass_len_host[q] & 3)) return AT_EINVAL;

@@ -122,13 +122,31 @@ def _prep_in(x):
     return x if x.is_contiguous() else x.contiguous()
 
 
-def _project_banded(x, a_kind, band, contrast, inverse, offset, scale, eps, out, N, channel_major_T):
+def _project_banded(x, a_kind, band, contrast, inverse, offset, scale, eps, out, N, channel_major_T, ld_out=None,
+                    phase_out=None, ld_phase=0, phase_offset=None, phase_scale=None):
     lane_filter, lane_start, weights = band.on(x.device)
     K = x.shape[-1]
     check(lib().at_mel_project_banded(ptr(x), a_kind, x.numel() // K, K, K, ptr(lane_filter), ptr(lane_start),
                                       ptr(weights), N, band.n_passes, band.pass_len.ctypes.data,
-                                      contrast_code(contrast), int(inverse), ptr(offset), ptr(scale), eps, ptr(out), N,
-                                      channel_major_T, stream_ptr()), "at_mel_project_banded")
+                                      contrast_code(contrast), int(inverse), ptr(offset), ptr(scale), eps, ptr(out),
+                                      N if ld_out is None else ld_out, channel_major_T, phase_out, ld_phase,
+                                      ptr(phase_offset), ptr(phase_scale), stream_ptr()), "at_mel_project_banded")
+    return out
+
+
+def polar_forward(x, band, contrast=None, mag_offset=None, mag_scale=None, eps=1.1920929e-07, phase_offset=None,
+                  phase_scale=None):
+    """Polar.forward in one pass: x (..., T, F) complex64 -> (..., T, 2, F) with [..., 0, :] =
+    normalise(contrast(|x| @ bank)) (banded bank with F filters) and [..., 1, :] = normalise(angle(x))."""
+    import ctypes
+    require_device(x)
+    x = _prep_in(x)
+    F = x.shape[-1]
+    assert band.N == F and band.eligible
+    out = torch.empty(x.shape[:-1] + (2, F), dtype=torch.float32, device=x.device)
+    phase_ptr = ctypes.c_void_p(out.data_ptr() + 4 * F)
+    _project_banded(x, 0, band, contrast, False, mag_offset, mag_scale, eps, out, F, 0, ld_out=2 * F,
+                    phase_out=phase_ptr, ld_phase=2 * F, phase_offset=phase_offset, phase_scale=phase_scale)
     return out
 
 

@@ -195,7 +195,25 @@ class SpectralRepresentation(AudioTransform):
         self.magnitude.scale_data(x)
         self.phase.scale_data(x)
 
+    def _one_pass(self, x):
+        """Polar with its default parts -- Magnitude over a banded bank of F filters next to a plain Phase,
+        stacked on dim -2 -- is one pass over the spectrum that writes the stacked tensor in place."""
+        mag, ph = self.magnitude, self.phase
+        if not (type(mag) is Magnitude and type(ph) is Phase and self.stack == -2 and x.is_complex() and x.is_cuda
+                and x.ndim >= 2 and mag.mel and mag.keep_nyquist and ph.keep_nyquist and not ph.unwrap):
+            return None
+        band = mag._band_of("mel_bank")
+        if band is None or band.N != x.shape[-1] or mag.mel_bank.shape[-2] != x.shape[-1]:
+            return None
+        mag._follow(x)
+        m_off, m_sc = mag._affine()
+        p_off, p_sc = ph._affine(x)
+        return ops.polar_forward(x, band, mag.contrast_mode, m_off, m_sc, mag._eps, p_off, p_sc)
+
     def forward(self, x: torch.Tensor) -> SpectralRepresentationType:
+        fused = self._one_pass(x)
+        if fused is not None:
+            return fused
         magnitude = self.magnitude(x)
         phase = self.phase(x)
         if self.stack is not None:

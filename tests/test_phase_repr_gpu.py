@@ -221,3 +221,29 @@ def test_reference_combination_chains(dev):
             assert float((x_inv - raw).abs().max()) < 0.05            # 8-bit companding error
         if name == "overlap+stft":
             assert y.shape[-1] == 513 and x_inv.shape[:-1] == raw.shape[:-1]
+
+
+def test_polar_one_pass_equals_parts(dev):
+    """Polar.forward with default parts runs as one kernel (banded magnitude + angle written into the stacked
+    tensor): same values as Magnitude and Phase run on their own, and as the oracle."""
+    gen = torch.Generator().manual_seed(17)
+    X = (torch.randn(3, 2, 21, 513, generator=gen) * torch.exp(2j * np.pi * torch.rand(3, 2, 21, 513, generator=gen))).to(torch.complex64)
+    Xd = X.to(dev)
+    pol = A.Polar().to(dev)
+    pol.scale_data(Xd)
+    assert pol._one_pass(Xd) is not None
+    y = pol(Xd)
+    assert y.shape == (3, 2, 21, 2, 513)
+    assert rel_max(cpu(y[..., 0, :]).numpy(), cpu(pol.magnitude(Xd)).numpy()) < TOL
+    assert rel_max(cpu(y[..., 1, :]).numpy(), cpu(pol.phase(Xd)).numpy()) < TOL
+    fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 513, 44100))
+    off, sc = O.magnitude_scale_stats(X, "log1p", "bipolar")
+    assert rel_max(cpu(y[..., 0, :]).numpy(), O.magnitude_forward(X, fwd, "log1p", off, sc).numpy()) < TOL
+    po, ps = O.normalize_stats(X.angle(), "bipolar")
+    assert rel_max(cpu(y[..., 1, :]).numpy(), O.affine(X.angle(), po, ps).numpy()) < TOL
+    # variants that do not qualify fall back to the generic path with the same values
+    for kw in ({"stack": None}, {"phase_args": {"mode": "bipolar", "unwrap": True}}, {"keep_nyquist": False}):
+        p2 = A.Polar(**kw).to(dev)
+        p2.scale_data(Xd)
+        assert p2._one_pass(Xd) is None
+        p2(Xd)

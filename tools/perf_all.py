@@ -73,6 +73,15 @@ if "phase" in which:
     mg_ = X.abs()
     report("polar->complex", timeit(lambda: ops.polar_to_complex(mg_, y)), 16 * F)
     del y, mg_
+if "polarfwd" in which:
+    pol = A.Polar().to(dev)
+    pol.scale_data(X[:8])
+    report("Polar.forward (one pass)", timeit(lambda: pol(X), n=5), 8 * 513 + 8 * 513)
+    pol.stack = -3                      # generic path: Magnitude, Phase, torch.stack
+    try:
+        report("Polar.forward (parts+stack)", timeit(lambda: torch.stack([pol.magnitude(X), pol.phase(X)], -2), n=5), 8 * 513 + 8 * 513)
+    finally:
+        pol.stack = -2
 if "sinebank" in which:
     mgs = X.abs()
     ph0 = 2 * torch.pi * torch.rand(513, 1)
