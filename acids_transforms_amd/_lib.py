@@ -26,6 +26,8 @@ _SIGNATURES = {
     "at_stft_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_stft_mel_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_int,
                             c_f, c_int, c_int, c_f, c_f, c_flt, c_f, c_f, c_f, c_int, c_f],
+    "at_stft_polar_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_int, c_f,
+                              c_int, c_f, c_f, c_flt, c_f, c_f, c_f, c_f],
     "at_istft_envelope_table": [c_f, c_int, c_int, c_f, c_f],
     "at_istft_workspace_bytes": [c_i64, c_i64, c_int, c_int],
     "at_istft": [c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_sz, c_f],

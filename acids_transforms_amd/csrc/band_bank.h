@@ -17,6 +17,13 @@ struct BandBank {
   int n_filters, n_passes;
   int pass_len[kMaxBandPasses];   // bins walked in each pass (multiple of 4)
 };
+// where the fused STFT kernel puts the two halves of a Polar representation
+struct PolarOut {
+  float* phase;
+  long long feat_ld, phase_ld;
+  const float* ph_offset;
+  const float* ph_scale;
+};
 constexpr int kMaxBandFloats = 8192;   // LDS copy of the weights (dynamic LDS): 64 * sum(pass_len) floats <= 32 KB
 
 }  // namespace at_hip

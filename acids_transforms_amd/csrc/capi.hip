@@ -5,22 +5,16 @@
 #include <vector>
 
 #include "../../include/acids_hip.h"
+#include "band_bank.h"
 #include "fft512.h"
 
 namespace at_hip {
 // stft1024.hip
 int launch_stft1024_fwd(const float*, long long, long long, long long, long long, int, int, const float*,
                         const float2*, float2*, float*, hipStream_t);
-struct BandBank {
-  const int* lane_filter;
-  const int* lane_start;
-  const float* weights;
-  int n_filters, n_passes;
-  int pass_len[16];
-};
 int launch_stft1024_h256_fwd(const float*, long long, long long, long long, long long, const float*, const float2*,
                              float2*, float*, const BandBank*, float*, const float*, const float*, float, int, int, int,
-                             hipStream_t);
+                             hipStream_t, const PolarOut* polar = nullptr);
 int launch_istft1024_ola(const float2*, const float*, const float*, long long, long long, const float*, const float*,
                          const float2*, float*, hipStream_t);
 int launch_irfft1024_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
@@ -150,6 +144,35 @@ int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_strid
   if (table_floats > 8192) return AT_EUNSUPPORTED;   // LDS copy of the band weights
   return launch_stft1024_h256_fwd(x, B, L, clip_stride, T, window, tw, (float2*)out_complex_or_null, phase_or_null, &bank,
                                   feat, offset, scale, eps, contrast, power2, feat_channel_major, (hipStream_t)stream);
+}
+
+int at_stft_polar_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
+                          const float* window, const int32_t* lane_filter, const int32_t* lane_start,
+                          const float* band_weights, int n_filters, int n_passes, const int32_t* pass_len_host,
+                          int contrast, const float* mag_offset, const float* mag_scale, float eps,
+                          const float* phase_offset, const float* phase_scale, float* out_stacked, void* stream) {
+  if (B < 0 || T < 0 || L < 0) return AT_EINVAL;
+  if (n_fft != 1024 || hop != 256 || (clip_stride & 1)) return AT_EUNSUPPORTED;
+  if (B * T == 0) return AT_OK;
+  if (!x || !window || !out_stacked || !lane_filter || !lane_start || !band_weights || !pass_len_host) return AT_EINVAL;
+  const int F = n_fft / 2 + 1;
+  if (n_filters != F || n_passes <= 0 || n_passes > 16 || n_filters > 64 * n_passes) return AT_EINVAL;   // stacked halves
+  if ((mag_offset == nullptr) != (mag_scale == nullptr) || (phase_offset == nullptr) != (phase_scale == nullptr))
+    return AT_EINVAL;
+  if (L <= n_fft / 2 || (((uintptr_t)window) & 7) || (((uintptr_t)band_weights) & 15)) return AT_EINVAL;
+  const float2* tw = twiddles_for_current_device();
+  if (!tw) return AT_ENOTINIT;
+  BandBank bank = {lane_filter, lane_start, band_weights, n_filters, n_passes, {0}};
+  long long table_floats = 0;
+  for (int q = 0; q < n_passes; ++q) {
+    if (pass_len_host[q] < 0 || pass_len_host[q] > 128 || (pass_len_host[q] & 3)) return AT_EINVAL;
+    bank.pass_len[q] = pass_len_host[q];
+    table_floats += 64LL * pass_len_host[q];
+  }
+  if (table_floats > 8192) return AT_EUNSUPPORTED;
+  const PolarOut polar = {out_stacked + F, 2LL * F, 2LL * F, phase_offset, phase_scale};
+  return launch_stft1024_h256_fwd(x, B, L, clip_stride, T, window, tw, nullptr, nullptr, &bank, out_stacked, mag_offset,
+                                  mag_scale, eps, contrast, 0, 0, (hipStream_t)stream, &polar);
 }
 
 int at_istft_envelope_table(const float* inv_window, int n_fft, int hop, float* env16, void* stream) {

@@ -159,6 +159,10 @@ struct FwdRunParams {
   int contrast;           // 0 none, 1 log1p, 2 log, 3 log10
   int power2;             // |X|^2 instead of |X|
   int feat_channel_major;
+  // POLAR: features and normalise(angle) rows written side by side into a stacked (B*T, 2, F) tensor
+  long long feat_ld, phase_ld;   // row strides (0: n_filters / F)
+  const float* ph_offset;        // Normalize affine of the phase half (device scalars or null)
+  const float* ph_scale;
 };
 
 // element n = lane + 64 m of the frame starting at padded position p0 (original index p0 - 512 + 2n)
@@ -188,7 +192,9 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
 // CMBUF (MEL != 0, channel-major features): number of passes whose outputs are kept for eight frames in
 // registers and written as 32 contiguous bytes per filter; 0 = every frame scatters 4-byte stores (each
 // lane its own row of the (B, N, T) tensor), which leaves partly written lines to be evicted and re-fetched.
-template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0>
+// POLAR (with MEL == 2): besides the features, normalise(angle X) of every bin goes to p.phase with row stride
+// p.phase_ld -- Compose(STFT + Polar) in one kernel, the complex spectrum never reaches HBM.
+template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false>
 __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
   __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
@@ -253,8 +259,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
 #pragma unroll
   for (int m = 0; m < 8; ++m) asm volatile("" : "+v"(raw[m].x), "+v"(raw[m].y));
   float2* row = p.out + (b * p.T + t0) * F;
-  float* prow = WRITE_PHASE ? p.phase + (b * p.T + t0) * F : nullptr;
-  float* frow = (MEL != 0) ? p.feat + (b * p.T + t0) * (long long)p.bank.n_filters : nullptr;
+  const long long feat_ld = (POLAR && p.feat_ld) ? p.feat_ld : (long long)p.bank.n_filters;
+  const long long phase_ld = (POLAR && p.phase_ld) ? p.phase_ld : F;
+  float* prow = (WRITE_PHASE || POLAR) ? p.phase + (b * p.T + t0) * phase_ld : nullptr;
+  float* frow = (MEL != 0) ? p.feat + (b * p.T + t0) * feat_ld : nullptr;
+  float ph_off = 0.f, ph_sc = 1.f;
+  if (POLAR && p.ph_offset) {
+    ph_off = *p.ph_offset;
+    ph_sc = *p.ph_scale;
+  }
   long long t_cur = t0;
   float cm[CMBUF ? CMBUF : 1][8];   // features of frames t_cur-7 .. t_cur (sliding), one row per pass
 #pragma unroll
@@ -305,6 +318,20 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
 #pragma unroll
       for (int m = 0; m < 8; ++m) prow[lane + 64 * m] = atan2f(v[m].y, v[m].x);
       prow += F;
+    }
+    if (POLAR) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        float ph = atan2f(v[m].y, v[m].x);
+        if (p.ph_offset) ph = (ph - ph_off) / ph_sc;
+        prow[lane + 64 * m] = ph;
+      }
+      if (lane == 0) {
+        float ph = atan2f(nyq.y, nyq.x);
+        if (p.ph_offset) ph = (ph - ph_off) / ph_sc;
+        prow[512] = ph;
+      }
+      prow += phase_ld;
     }
     if (MEL != 0) {
       // |X| (or |X|^2) of this frame into the wave's LDS slab (free again after the FFT), then every lane
@@ -376,7 +403,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
         for (int q = 0; q < p.bank.n_passes; ++q) one_pass(q, std::integral_constant<int, -1>());
       }
       wave_lds_sync();
-      frow += p.bank.n_filters;
+      frow += feat_ld;
       ++t_cur;
     }
     nyq_pending = nyq;
@@ -756,13 +783,18 @@ int launch_stft1024_fwd(const float* x, long long B, long long L, long long clip
 int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long clip_stride, long long T,
                              const float* window, const float2* tw, float2* out, float* phase, const BandBank* bank,
                              float* feat, const float* offset, const float* scale, float eps, int contrast, int power2,
-                             int feat_channel_major, hipStream_t stream) {
+                             int feat_channel_major, hipStream_t stream, const PolarOut* polar) {
   FwdRunParams p = {};
   p.x = x; p.window = window; p.tw = tw; p.out = out; p.phase = phase;
   p.B = B; p.L = L; p.clip_stride = clip_stride; p.T = T;
   if (bank) {
     p.bank = *bank; p.feat = feat; p.offset = offset; p.scale = scale; p.eps = eps; p.contrast = contrast;
     p.power2 = power2; p.feat_channel_major = feat_channel_major;
+  }
+  if (polar) {
+    if (!bank || out) return -1;
+    p.phase = polar->phase; p.feat_ld = polar->feat_ld; p.phase_ld = polar->phase_ld;
+    p.ph_offset = polar->ph_offset; p.ph_scale = polar->ph_scale;
   }
   if (B * T == 0) return 0;
   size_t dyn_lds = 0;
@@ -780,8 +812,9 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     kernel = phase ? stft1024_h256_fwd_kernel<true, 0, 4, false> : stft1024_h256_fwd_kernel<false, 0, 4, false>;
   } else {
     NW = 8;
-    if (!out && feat_channel_major && bank->n_passes == 1) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 1>;
-    else if (!out && feat_channel_major && bank->n_passes == 2) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 2>;
+    if (!out && !polar && feat_channel_major && bank->n_passes == 1) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 1>;
+    else if (!out && !polar && feat_channel_major && bank->n_passes == 2) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 2>;
+    else if (!out && polar) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, true>;
     else if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true>;
     else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true> : stft1024_h256_fwd_kernel<false, 1, 8, true>;
   }

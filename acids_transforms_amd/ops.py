@@ -532,3 +532,20 @@ def resample_sinc(x, orig, new, width, filters):
     check(lib().at_resample_sinc(ptr(x), rows, L, orig, new, width, ptr(filters), out_len, ptr(out), stream_ptr()),
           "at_resample_sinc")
     return out
+
+
+def stft_polar_forward(x, window, band, contrast=None, mag_offset=None, mag_scale=None, eps=1.1920929e-07,
+                       phase_offset=None, phase_scale=None):
+    """Compose(STFT -> Polar) in one kernel: x (B, L) -> (B, T, 2, F): [.., 0, :] = normalise(contrast(|X| @ bank)),
+    [.., 1, :] = normalise(angle X).  n_fft = 1024, hop = 256, bank with F = 513 banded filters."""
+    require_device(x, window)
+    x = _f32c(x)
+    B, L = x.shape
+    T = 1 + L // 256
+    lane_filter, lane_start, weights = band.on(x.device)
+    out = torch.empty((B, T, 2, 513), dtype=torch.float32, device=x.device)
+    check(lib().at_stft_polar_forward(ptr(x), B, L, L, T, 1024, 256, ptr(window), ptr(lane_filter), ptr(lane_start),
+                                      ptr(weights), band.N, band.n_passes, band.pass_len.ctypes.data,
+                                      contrast_code(contrast), ptr(mag_offset), ptr(mag_scale), eps, ptr(phase_offset),
+                                      ptr(phase_scale), ptr(out), stream_ptr()), "at_stft_polar_forward")
+    return out

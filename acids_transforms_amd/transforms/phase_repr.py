@@ -210,6 +210,35 @@ class SpectralRepresentation(AudioTransform):
         p_off, p_sc = ph._affine(x)
         return ops.polar_forward(x, band, mag.contrast_mode, m_off, m_sc, mag._eps, p_off, p_sc)
 
+    # -- fusion with the preceding STFT / DGT stage (ComposeAudioTransform.forward) -----------------------
+    def can_fuse_with(self, stage, x: torch.Tensor) -> bool:
+        """True when `stage` (offline STFT/DGT, n_fft=1024, hop=256) followed by this Polar can run as one kernel
+        on the audio x: the complex spectrum is then never written."""
+        mag, ph = self.magnitude, self.phase
+        if not (type(mag) is Magnitude and type(ph) is Phase and self.stack == -2 and mag.keep_nyquist
+                and ph.keep_nyquist and not ph.unwrap):
+            return False
+        if not mag.can_fuse_with(stage, x):
+            return False
+        band = mag._banded()
+        return band is not None and band.N == 513
+
+    def forward_fused(self, stage, x: torch.Tensor):
+        from ..utils.misc import reshape_batches
+        mag, ph = self.magnitude, self.phase
+        stage._follow(x)
+        mag._follow(x)
+        m_off, m_sc = mag._affine()
+        p_off, p_sc = ph._affine(x)
+        xb, batch_shape = reshape_batches(x, -1)
+        y = ops.stft_polar_forward(xb, stage.window[:1024], mag._banded(), mag.contrast_mode, m_off, m_sc, mag._eps,
+                                   p_off, p_sc)
+        # the stage's phase buffer (keep_input inversion) is the phase half of the result, de-normalised on demand
+        half = y[..., 1, :]
+        stage._replace_phase_buffer(
+            (lambda: ops.affine(half, p_off, p_sc, inverse=True)) if p_off is not None else (lambda: half.contiguous()))
+        return y.reshape(batch_shape + y.shape[-3:])
+
     def forward(self, x: torch.Tensor) -> SpectralRepresentationType:
         fused = self._one_pass(x)
         if fused is not None:

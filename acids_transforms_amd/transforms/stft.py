@@ -170,7 +170,8 @@ class STFT(AudioTransform):
         src = self.__dict__.get("_phase_src")
         if src is not None:
             self.__dict__["_phase_src"] = None
-            self._buffers["phase_buffer"] = ops.angle(src)
+            # a complex spectrum, or a deferred computation (fused paths that never wrote the spectrum)
+            self._buffers["phase_buffer"] = src() if callable(src) else ops.angle(src)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         self._materialise_phase()

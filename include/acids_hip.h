@@ -75,6 +75,16 @@ int at_stft_mel_forward(const float *x, int64_t B, int64_t L, int64_t clip_strid
                         float *out_complex_or_null, float *phase_or_null, float *feat, int feat_channel_major,
                         void *stream);
 
+/* Compose(STFT -> Polar) in one kernel (spectral_repr.py:511-523 behind stft.py:98-104): framing + rFFT, then
+ * out[r, 0, :] = normalise(contrast(|X| @ bank)) (banded bank with F = 513 filters, tables as above) and
+ * out[r, 1, :] = normalise(angle X), r = clip * T + frame; out_stacked: (B*T, 2, F).  The complex spectrum
+ * is never written. */
+int at_stft_polar_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
+                          const float *window, const int32_t *lane_filter, const int32_t *lane_start,
+                          const float *band_weights, int n_filters, int n_passes, const int32_t *pass_len_host,
+                          int contrast, const float *mag_offset, const float *mag_scale, float eps,
+                          const float *phase_offset, const float *phase_scale, float *out_stacked, void *stream);
+
 /* ---- K3/K5/K15: inverse ------------------------------------------------ */
 /* 16 x hop table of window^2 sums used by at_istft for n_fft=1024, hop=256
  * (torch.istft's window envelope; stft.py:126-127).  env16: 16*hop floats. */

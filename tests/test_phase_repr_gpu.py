@@ -247,3 +247,41 @@ def test_polar_one_pass_equals_parts(dev):
         p2.scale_data(Xd)
         assert p2._one_pass(Xd) is None
         p2(Xd)
+
+
+def test_compose_stft_polar_is_one_kernel(dev):
+    """ComposeAudioTransform(STFT|DGT + Polar) with default parts: framing, FFT, banded magnitude and phase in a
+    single kernel that never writes the complex spectrum.  Same values as stage by stage; the STFT stage's
+    phase buffer (keep_input inversion) is recovered from the phase half of the result."""
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(2, 3, 10240, generator=gen) * 0.1
+    xd = x.to(dev)
+    for cls in (A.STFT, A.DGT):
+        st, pol = cls().to(dev), A.Polar().to(dev)
+        comp = st + pol
+        comp.scale_data(xd)
+        assert pol.can_fuse_with(st, xd)
+        y = comp(xd)                                   # fused
+        X = cls().to(dev)(xd)
+        y2 = pol(X)                                    # stage by stage (one-pass Polar over the stored spectrum)
+        assert y.shape == y2.shape == (2, 3, 41, 2, 513)
+        assert rel_max(cpu(y[..., 0, :]).numpy(), cpu(y2[..., 0, :]).numpy()) < TOL
+        # phases: +pi and -pi are the same angle (DC / Nyquist are real, the sign of their zero imaginary part is
+        # not significant) -> compare the de-normalised halves on the circle
+        a = cpu(pol.phase.invert(y[..., 1, :].contiguous()))
+        b = cpu(pol.phase.invert(y2[..., 1, :].contiguous()))
+        big = cpu(X.abs()) > 1e-2          # the angle of a near-zero bin is ill-conditioned
+        assert float(torch.angle(torch.exp(1j * (a - b)))[big].abs().max()) < 1e-4
+        # side effect of the STFT stage: phase_buffer == angle(X) where the magnitude is significant
+        d = torch.angle(torch.exp(1j * (cpu(st.phase_buffer).reshape(X.shape) - cpu(X).angle())))
+        assert float(d[big].abs().max()) < 1e-3
+        # keep_input inversion right after the fused forward uses that phase
+        mag = X.abs()
+        ya = st.invert(mag, inversion_mode="keep_input")
+        yb = cls().to(dev).invert(X)
+        assert rel_max(cpu(ya).numpy(), cpu(yb).numpy()) < 1e-4
+    # not fusable: odd length, stack=None, unwrapped phase
+    st = A.STFT().to(dev)
+    assert not A.Polar().to(dev).can_fuse_with(st, torch.zeros(2, 9001, device=dev))
+    assert not A.Polar(stack=None).to(dev).can_fuse_with(st, xd)
+    assert not A.Polar(phase_args={"mode": "bipolar", "unwrap": True}).to(dev).can_fuse_with(st, xd)

@@ -82,6 +82,12 @@ if "polarfwd" in which:
         report("Polar.forward (parts+stack)", timeit(lambda: torch.stack([pol.magnitude(X), pol.phase(X)], -2), n=5), 8 * 513 + 8 * 513)
     finally:
         pol.stack = -2
+if "stftpolar" in which:
+    pol2 = A.Polar().to(dev)
+    pol2.scale_data(X[:8])
+    comp = m + pol2
+    report("STFT+Polar (one kernel)", timeit(lambda: comp(x), n=5), 1024 + 8 * 513)
+    report("STFT then Polar", timeit(lambda: pol2(m(x)), n=5), 1024 + 8 * 513)
 if "sinebank" in which:
     mgs = X.abs()
     ph0 = 2 * torch.pi * torch.rand(513, 1)
