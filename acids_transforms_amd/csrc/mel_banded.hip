@@ -36,6 +36,9 @@ struct BandedParams {
   long long ld_phase;
   const float* ph_offset;
   const float* ph_scale;
+  // inverse only: phase_in != null turns the output into complex64, out[r, f] = acc * exp(i * denormalise(
+  // phase_in[r * ld_phase + f])) -- Polar.invert (spectral_repr.py:441-451) in one pass over the stacked tensor
+  const float* phase_in;
 };
 
 constexpr int kBandedWaves = 8;     // waves per workgroup, sharing the LDS weight table
@@ -161,7 +164,13 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
           acc = banded_contrast_fwd(acc, p.contrast, p.eps);
           if (p.offset) acc = (acc - off) / sc;
         }
-        if (p.T > 0) {
+        if (p.phase_in) {
+          float ph = p.phase_in[r * p.ld_phase + f];
+          if (p.ph_offset) ph = __fadd_rn(__fmul_rn(ph, ph_sc), ph_off);
+          float sn, cs;
+          sincosf(ph, &sn, &cs);
+          reinterpret_cast<float2*>(p.out)[r * p.ld_out + f] = make_float2(acc * cs, acc * sn);
+        } else if (p.T > 0) {
           const long long b = r / p.T, t = r - b * p.T;
           p.out[(b * p.bank.n_filters + f) * p.T + t] = acc;
         } else {
@@ -232,7 +241,7 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
                           const int32_t* lane_start, const float* band_weights, int n_filters, int n_passes,
                           const int32_t* pass_len_host, int contrast, int inverse, const float* offset, const float* scale,
                           float eps, float* out, int64_t ld_out, int64_t T_transposed, float* phase_out, int64_t ld_phase,
-                          const float* phase_offset, const float* phase_scale, void* stream) {
+                          const float* phase_offset, const float* phase_scale, const float* phase_in, void* stream) {
   if (rows < 0 || K <= 0 || n_filters <= 0) return AT_EINVAL;
   if (rows == 0) return AT_OK;
   if (!A || !out || !lane_filter || !lane_start || !band_weights || !pass_len_host) return AT_EINVAL;
@@ -241,6 +250,7 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
   if (inverse && a_kind != A_REAL) return AT_EINVAL;
   if (phase_out && a_kind >= A_REAL) return AT_EINVAL;
+  if (phase_in && (!inverse || phase_out || T_transposed)) return AT_EINVAL;
   if ((phase_offset == nullptr) != (phase_scale == nullptr)) return AT_EINVAL;
   if (K > kRowFloats || (((uintptr_t)band_weights) & 15)) return AT_EUNSUPPORTED;
   BandedParams p = {};
@@ -250,6 +260,7 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
   p.bank.n_filters = n_filters; p.bank.n_passes = n_passes;
   p.K = K; p.a_kind = a_kind; p.contrast = contrast; p.inverse = inverse; p.eps = eps;
   p.phase_out = phase_out; p.ld_phase = ld_phase; p.ph_offset = phase_offset; p.ph_scale = phase_scale;
+  p.phase_in = phase_in;
   size_t table_floats = 0;
   for (int q = 0; q < n_passes; ++q) {
     if (pass_len_host[q] < 0 || pass_len_host[q] > 128 || (pass_len_host[q] & 3)) return AT_EINVAL;

@@ -123,14 +123,33 @@ def _prep_in(x):
 
 
 def _project_banded(x, a_kind, band, contrast, inverse, offset, scale, eps, out, N, channel_major_T, ld_out=None,
-                    phase_out=None, ld_phase=0, phase_offset=None, phase_scale=None):
+                    phase_out=None, ld_phase=0, phase_offset=None, phase_scale=None, phase_in=None, rows=None, lda=None):
     lane_filter, lane_start, weights = band.on(x.device)
-    K = x.shape[-1]
-    check(lib().at_mel_project_banded(ptr(x), a_kind, x.numel() // K, K, K, ptr(lane_filter), ptr(lane_start),
+    K = band.K
+    check(lib().at_mel_project_banded(ptr(x), a_kind, x.numel() // K if rows is None else rows, K if lda is None else lda,
+                                      K, ptr(lane_filter), ptr(lane_start),
                                       ptr(weights), N, band.n_passes, band.pass_len.ctypes.data,
                                       contrast_code(contrast), int(inverse), ptr(offset), ptr(scale), eps, ptr(out),
                                       N if ld_out is None else ld_out, channel_major_T, phase_out, ld_phase,
-                                      ptr(phase_offset), ptr(phase_scale), stream_ptr()), "at_mel_project_banded")
+                                      ptr(phase_offset), ptr(phase_scale), phase_in, stream_ptr()),
+          "at_mel_project_banded")
+    return out
+
+
+def polar_inverse(y, inv_band, contrast=None, mag_offset=None, mag_scale=None, eps=1.1920929e-07, phase_offset=None,
+                  phase_scale=None):
+    """Polar.invert in one pass: y (..., T, 2, F) stacked -> (..., T, F) complex64 =
+    (invert_contrast(y[.., 0, :] * s + o) @ inverse_bank) * exp(i * (y[.., 1, :] * ps + po))."""
+    import ctypes
+    require_device(y)
+    y = _f32c(y)
+    F = y.shape[-1]
+    assert inv_band.K == F and inv_band.N == F and inv_band.eligible
+    rows = y.numel() // (2 * F)
+    out = torch.empty(y.shape[:-2] + (F,), dtype=torch.complex64, device=y.device)
+    phase_ptr = ctypes.c_void_p(y.data_ptr() + 4 * F)
+    _project_banded(y, 2, inv_band, contrast, True, mag_offset, mag_scale, eps, out, F, 0, ld_out=F, ld_phase=2 * F,
+                    phase_offset=phase_offset, phase_scale=phase_scale, phase_in=phase_ptr, rows=rows, lda=2 * F)
     return out
 
 

@@ -254,7 +254,26 @@ class SpectralRepresentation(AudioTransform):
             return x[0], x[1]
         return x.select(self.stack, 0), x.select(self.stack, 1)
 
+    def _one_pass_invert(self, x):
+        """The mirror image of `_one_pass`: de-normalise, invert the contrast, project through the banded inverse
+        bank and attach exp(i phase), reading the stacked tensor once."""
+        mag, ph = self.magnitude, self.phase
+        if not (type(mag) is Magnitude and type(ph) is Phase and self.stack == -2 and isinstance(x, torch.Tensor)
+                and x.is_cuda and x.ndim >= 3 and x.shape[-2] == 2 and mag.mel and mag.keep_nyquist and ph.keep_nyquist):
+            return None
+        band = mag._band_of("inverse_mel_bank")
+        if band is None or band.K != x.shape[-1] or band.N != x.shape[-1]:
+            return None
+        mag._follow(x)
+        m_off, m_sc = mag._affine()
+        p_off, p_sc = ph._affine(x)
+        return ops.polar_inverse(x, band, mag.contrast_mode, m_off, m_sc, mag._eps, p_off, p_sc)
+
     def invert(self, x, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        if type(self) is Polar:
+            fused = self._one_pass_invert(x)
+            if fused is not None:
+                return fused
         mag, phase = self._split(x)
         mag = self.magnitude.invert(mag)
         phase = self.phase.invert(phase)

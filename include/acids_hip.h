@@ -214,13 +214,15 @@ int at_argmax_last(const int64_t *x_i64, const float *x_f32, int64_t rows, int c
  * one filter per pass -- the walk tables are those of at_stft_mel_forward (utils/banded.py).  HBM-bound (input
  * row in, n_filters floats out) where the dense contraction is MFMA-bound.  Arguments as at_mel_project.
  * phase_out != NULL (complex input): also writes normalise(angle(x)) with row stride ld_phase -- Polar.forward
- * (spectral_repr.py:432-439) fills its stacked (.., T, 2, F) result in one pass over the spectrum. */
+ * (spectral_repr.py:432-439) fills its stacked (.., T, 2, F) result in one pass over the spectrum.
+ * phase_in != NULL (inverse only): `out` is complex64, out[r, f] = acc * exp(i * (phase_in[r*ld_phase + f] *
+ * phase_scale + phase_offset)) -- Polar.invert (spectral_repr.py:441-451) in one pass. */
 int at_mel_project_banded(const void *A, int a_kind, int64_t rows, int64_t lda, int K, const int32_t *lane_filter,
                           const int32_t *lane_start, const float *band_weights, int n_filters, int n_passes,
                           const int32_t *pass_len_host, int contrast, int inverse, const float *offset,
                           const float *scale, float eps, float *out, int64_t ld_out, int64_t T_transposed,
                           float *phase_out, int64_t ld_phase, const float *phase_offset, const float *phase_scale,
-                          void *stream);
+                          const float *phase_in, void *stream);
 
 /* ---- phase-side representations ------------------------------------------ */
 /* Scan along the frame axis of a (B, T, F) spectrum, one of X_complex / phase given (the angle is taken

@@ -241,6 +241,12 @@ def test_polar_one_pass_equals_parts(dev):
     assert rel_max(cpu(y[..., 0, :]).numpy(), O.magnitude_forward(X, fwd, "log1p", off, sc).numpy()) < TOL
     po, ps = O.normalize_stats(X.angle(), "bipolar")
     assert rel_max(cpu(y[..., 1, :]).numpy(), O.affine(X.angle(), po, ps).numpy()) < TOL
+    # invert mirrors it: one pass over the stacked tensor == Magnitude.invert, Phase.invert, mag * exp(i phase)
+    assert pol._one_pass_invert(y) is not None
+    Xi = pol.invert(y)
+    parts = ops.polar_to_complex(pol.magnitude.invert(y[..., 0, :]), pol.phase.invert(y[..., 1, :]))
+    assert Xi.dtype == torch.complex64 and Xi.shape == X.shape
+    assert rel_max(cpu(Xi).numpy(), cpu(parts).numpy()) < TOL
     # variants that do not qualify fall back to the generic path with the same values
     for kw in ({"stack": None}, {"phase_args": {"mode": "bipolar", "unwrap": True}}, {"keep_nyquist": False}):
         p2 = A.Polar(**kw).to(dev)

@@ -74,9 +74,14 @@ if "phase" in which:
     report("polar->complex", timeit(lambda: ops.polar_to_complex(mg_, y)), 16 * F)
     del y, mg_
 if "polarfwd" in which:
+    from acids_transforms_amd import ops
     pol = A.Polar().to(dev)
     pol.scale_data(X[:8])
     report("Polar.forward (one pass)", timeit(lambda: pol(X), n=5), 8 * 513 + 8 * 513)
+    Yp = pol(X)
+    report("Polar.invert (one pass)", timeit(lambda: pol.invert(Yp), n=5), 8 * 513 + 8 * 513)
+    report("Polar.invert (parts)", timeit(lambda: ops.polar_to_complex(pol.magnitude.invert(Yp[..., 0, :]), pol.phase.invert(Yp[..., 1, :])), n=5), 8 * 513 + 8 * 513)
+    del Yp
     pol.stack = -3                      # generic path: Magnitude, Phase, torch.stack
     try:
         report("Polar.forward (parts+stack)", timeit(lambda: torch.stack([pol.magnitude(X), pol.phase(X)], -2), n=5), 8 * 513 + 8 * 513)
