@@ -88,8 +88,9 @@ class MFCC(AudioTransform):
     def forward(self, x: torch.Tensor):
         self._follow(x)
         xb, batch_shape = reshape_batches(x, -1)
-        if (self.n_mfcc is None and self.n_fft == 1024 and self.hop_length == 256 and self._band.eligible
-                and xb.dtype == torch.float32 and xb.shape[-1] > 512 and not (xb.shape[-1] & 1)):
+        fusable = (self.n_fft == 1024 and self.hop_length == 256 and self._band.eligible
+                   and xb.dtype == torch.float32 and xb.shape[-1] > 512 and not (xb.shape[-1] & 1))
+        if fusable and self.n_mfcc is None:
             # one kernel, audio -> mel power: the spectrum never goes to HBM
             off = sc = None
             if self.norm is not None:
@@ -97,6 +98,15 @@ class MFCC(AudioTransform):
             _, _, mel = ops.stft_mel_forward(xb, self.window, self._band, None, off, sc, power=int(self.power),
                                              want_spectrum=False, channel_major=True)
             return mel.reshape(batch_shape + mel.shape[-2:])
+        if fusable:
+            # extension (n_mfcc): the same kernel emits log(mel power), the DCT is a small second contraction
+            _, _, logmel = ops.stft_mel_forward(xb, self.window, self._band, "log", None, None, eps=1e-10,
+                                                power=int(self.power), want_spectrum=False)
+            off = sc = None
+            if self.norm is not None:
+                off, sc = self.norm._params(x)
+            out = ops.mel_forward_real(logmel, self.dct, off, sc, channel_major_T=logmel.shape[-2])
+            return out.reshape(batch_shape + out.shape[-2:])
         X = ops.stft_forward(xb, self.window, self.n_fft, self.hop_length, center=True)     # (B, T, F)
         T = X.shape[-2]
         off = sc = None
@@ -107,7 +117,8 @@ class MFCC(AudioTransform):
                                   band=self._band)
             return mel.reshape(batch_shape + mel.shape[-2:])
         # extension: MFCC = DCT-II(10 log10(mel power)); ln -> dB factor is folded into the DCT matrix
-        logmel = ops.mel_forward(X, self.fbank, "log", None, None, eps=1e-10, power=int(self.power))   # (B, T, n_mels)
+        logmel = ops.mel_forward(X, self.fbank, "log", None, None, eps=1e-10, power=int(self.power),
+                                 band=self._band)                                               # (B, T, n_mels)
         if self.norm is not None:
             off, sc = self.norm._params(x)
         out = ops.mel_forward_real(logmel, self.dct, off, sc, channel_major_T=T)

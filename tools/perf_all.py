@@ -73,6 +73,9 @@ if "phase" in which:
     mg_ = X.abs()
     report("polar->complex", timeit(lambda: ops.polar_to_complex(mg_, y)), 16 * F)
     del y, mg_
+if "mfcc40" in which:
+    mf40 = A.MFCC(n_mfcc=40).to(dev)
+    report("MFCC(n_mfcc=40)", timeit(lambda: mf40(x)), 1024 + 4 * 40)
 if "polarfwd" in which:
     from acids_transforms_amd import ops
     pol = A.Polar().to(dev)
