@@ -44,6 +44,7 @@ _SIGNATURES = {
                        c_i64, c_f],
     "at_mel_project_banded": [c_f, c_int, c_i64, c_i64, c_int, c_f, c_f, c_f, c_int, c_int, c_f, c_int, c_int, c_f, c_f,
                               c_flt, c_f, c_i64, c_i64, c_f, c_i64, c_f, c_f, c_f, c_f],
+    "at_project_small": [c_f, c_i64, c_int, c_f, c_int, c_f, c_f, c_f, c_i64, c_f],
     "at_mag_pointwise": [c_f, c_int, c_i64, c_int, c_int, c_f, c_f, c_flt, c_f, c_f],
     "at_stats_workspace_bytes": [],
     "at_stats": [c_f, c_int, c_i64, c_int, c_flt, c_f, c_f, c_sz, c_f],

@@ -274,3 +274,122 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
 }
 
 }  // extern "C"
+
+// ---- small dense real projection: out = normalise(x @ W), K <= 128, N <= 64 (the DCT-II behind MFCC(n_mfcc)) ----
+// One wavefront per row: lane n keeps column n of W in registers for the whole launch (K VGPRs), the row is
+// broadcast from LDS four values per ds_read_b128, K multiply-adds per lane.  The MFMA projection of mel.hip
+// wastes most of a 128-column block on such a narrow matrix (0.56 ms for 706 560 rows of 128 -> 40; this: HBM).
+namespace at_hip {
+
+struct SmallProjParams {
+  const float* x;       // rows x K
+  const float* W;       // K x N row-major
+  float* out;
+  const float* offset;
+  const float* scale;
+  long long rows, T;    // T > 0: channel-major store out[(r / T) * N * T + n * T + r % T]
+  long long rows_per_wave;
+  int K, N;
+};
+
+template <int KQ>   // KQ = ceil(K / 4) quads of the row, <= 32
+__global__ __launch_bounds__(256) void small_proj_kernel(SmallProjParams p) {
+  __shared__ float4 rowbuf[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w[4 * KQ];
+#pragma unroll
+  for (int k = 0; k < 4 * KQ; ++k) w[k] = (k < p.K && lane < p.N) ? p.W[(long long)k * p.N + lane] : 0.0f;
+  float off = 0.f, sc = 1.f;
+  if (p.offset) {
+    off = *p.offset;
+    sc = *p.scale;
+  }
+  long long r = ((long long)blockIdx.x * 4 + wave) * p.rows_per_wave;
+  long long r_end = r + p.rows_per_wave;
+  if (r_end > p.rows) r_end = p.rows;
+  float* buf = reinterpret_cast<float*>(rowbuf[wave]);
+  // channel-major output: every lane owns one row of the (.., N, T) tensor; eight frames are kept in registers
+  // and stored as 32 contiguous bytes (a 4-byte store per frame leaves partly written lines to be re-fetched)
+  float cm[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cm[k] = 0.f;
+  long long run_t0 = (p.T > 0) ? r % p.T : 0;     // first frame of this wave's rows inside the current clip
+  const int k0 = 2 * lane;              // a row is K <= 128 floats: two per lane
+  auto fetch = [&](long long row, float& a, float& b) {
+    const float* src = p.x + row * p.K;
+    a = (k0 < p.K) ? src[k0] : 0.0f;
+    b = (k0 + 1 < p.K) ? src[k0 + 1] : 0.0f;
+  };
+  float c0 = 0.f, c1 = 0.f, n0[3] = {0.f, 0.f, 0.f}, n1[3] = {0.f, 0.f, 0.f};
+  if (r < r_end) fetch(r, c0, c1);
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    if (r + 1 + d < r_end) fetch(r + 1 + d, n0[d], n1[d]);
+  for (; r < r_end; ++r) {
+    // stage the current row; rows r+1 .. r+3 are already on their way, request r+4
+    buf[k0] = c0;
+    buf[k0 + 1] = c1;
+    c0 = n0[0]; c1 = n1[0];
+    n0[0] = n0[1]; n1[0] = n1[1];
+    n0[1] = n0[2]; n1[1] = n1[2];
+    if (r + 4 < r_end) fetch(r + 4, n0[2], n1[2]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const float4 v = rowbuf[wave][q];            // same address on every lane: LDS broadcast
+      acc = fmaf(v.x, w[4 * q], acc);
+      acc = fmaf(v.y, w[4 * q + 1], acc);
+      acc = fmaf(v.z, w[4 * q + 2], acc);
+      acc = fmaf(v.w, w[4 * q + 3], acc);
+    }
+    if (p.offset) acc = (acc - off) / sc;
+    if (p.T > 0) {
+      const long long b = r / p.T, t = r - b * p.T;
+      if (t == 0) run_t0 = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) cm[k] = cm[k + 1];
+      cm[7] = acc;
+      if (((t & 7) == 7 || t == p.T - 1 || r == r_end - 1) && lane < p.N) {
+        long long first = t & ~7LL;                 // frames [first, t] are new since the last flush
+        if (first < run_t0) first = run_t0;
+        float* dst = p.out + (b * p.N + lane) * p.T + (t - 7);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (t - 7 + k >= first) dst[k] = cm[k];
+      }
+    } else if (lane < p.N) {
+      p.out[r * p.N + lane] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+}  // namespace at_hip
+
+extern "C" int at_project_small(const float* x, int64_t rows, int K, const float* W, int N, const float* offset,
+                                const float* scale, float* out, int64_t T_transposed, void* stream) {
+  using namespace at_hip;
+  if (rows < 0 || K <= 0 || N <= 0) return AT_EINVAL;
+  if (rows == 0) return AT_OK;
+  if (!x || !W || !out) return AT_EINVAL;
+  if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
+  if (K > 128 || N > 64) return AT_EUNSUPPORTED;
+  SmallProjParams p = {x, W, out, offset, scale, rows, T_transposed, 0, K, N};
+  const long long waves_target = 256LL * 32;
+  long long rpw = (rows + waves_target - 1) / waves_target;
+  if (rpw < 4) rpw = 4;
+  p.rows_per_wave = rpw;
+  const long long waves = (rows + rpw - 1) / rpw;
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int kq = (K + 3) / 4;
+  if (kq <= 8) hipLaunchKernelGGL(small_proj_kernel<8>, grid, block, 0, s, p);
+  else if (kq <= 16) hipLaunchKernelGGL(small_proj_kernel<16>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(small_proj_kernel<32>, grid, block, 0, s, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}

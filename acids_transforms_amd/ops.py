@@ -257,6 +257,11 @@ def mel_forward_real(x, mat, offset=None, scale=None, channel_major_T=0):
         out = torch.empty(x.shape[:-2] + (N, channel_major_T), dtype=torch.float32, device=x.device)
     else:
         out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    mat = _f32c(mat)
+    if K <= 128 and N <= 64:      # narrow matrix: columns in registers, one wavefront per row
+        check(lib().at_project_small(ptr(x), rows, K, ptr(mat), N, ptr(offset), ptr(scale), ptr(out), channel_major_T,
+                                     stream_ptr()), "at_project_small")
+        return out
     check(lib().at_mel_project(ptr(x), 2, rows, K, K, ptr(mat), N, N, 0, 0, ptr(offset), ptr(scale), 0.0, ptr(out), N,
                                channel_major_T, stream_ptr()), "at_mel_project")
     return out

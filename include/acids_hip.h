@@ -224,6 +224,11 @@ int at_mel_project_banded(const void *A, int a_kind, int64_t rows, int64_t lda, 
                           float *phase_out, int64_t ld_phase, const float *phase_offset, const float *phase_scale,
                           const float *phase_in, void *stream);
 
+/* normalise(x @ W) for a small real matrix (K <= 128, N <= 64): the DCT-II behind MFCC(n_mfcc); one wavefront
+ * per row with W's columns in registers.  out: (rows, N), or channel-major (rows/T, N, T) when T_transposed > 0. */
+int at_project_small(const float *x, int64_t rows, int K, const float *W, int N, const float *offset,
+                     const float *scale, float *out, int64_t T_transposed, void *stream);
+
 /* ---- phase-side representations ------------------------------------------ */
 /* Scan along the frame axis of a (B, T, F) spectrum, one of X_complex / phase given (the angle is taken
  * inside), optional per-frame weight frame_window[T] and Normalize affine (device scalars) applied last:
