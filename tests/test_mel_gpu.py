@@ -314,3 +314,25 @@ def test_banded_projection_equals_dense_contraction(dev):
         fwd, inv = O.magnitude_banks(O.melscale_fbanks(F, 0.0, 22050.0, n_mels, 44100))
         want = O.magnitude_forward(X, fwd, "log1p")
         assert rel_max(cpu(m.__class__(n_fft=n_fft, n_mels=n_mels, mode=None).to(dev)(Xd)), want.numpy()) < TOL
+
+
+def test_small_projection_shapes(dev):
+    """at_project_small (the MFCC DCT): every K <= 128 / N <= 64 shape class, row-major and channel-major output
+    with frame counts that are not multiples of the 8-frame store window, with and without normalisation."""
+    from acids_transforms_amd import ops
+    gen = torch.Generator().manual_seed(51)
+    off = torch.tensor(0.25, device=dev)
+    sc = torch.tensor(3.0, device=dev)
+    for (B, T, K, N) in [(3, 17, 128, 40), (1, 1, 128, 40), (5, 8, 64, 13), (2, 23, 20, 64), (7, 3, 128, 1), (2, 1000, 33, 7)]:
+        x = torch.randn(B, T, K, generator=gen)
+        W = torch.randn(K, N, generator=gen)
+        want = (x.double() @ W.double()).float()
+        for (o, s_) in ((None, None), (off, sc)):
+            ref = want if o is None else (want - 0.25) / 3.0
+            y = ops.mel_forward_real(x.to(dev), W.to(dev), o, s_)
+            assert y.shape == (B, T, N) and rel_max(cpu(y), ref.numpy()) < TOL, (B, T, K, N)
+            yc = ops.mel_forward_real(x.to(dev), W.to(dev), o, s_, channel_major_T=T)
+            assert yc.shape == (B, N, T) and rel_max(cpu(yc), ref.transpose(-2, -1).numpy()) < TOL, (B, T, K, N)
+    big = torch.randn(4, 10, 200, generator=gen)           # K > 128: the MFMA contraction takes over
+    Wb = torch.randn(200, 30, generator=gen)
+    assert rel_max(cpu(ops.mel_forward_real(big.to(dev), Wb.to(dev))), (big @ Wb).numpy()) < 1e-4
