@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
       hn -= 1;
       int c;
       if (hn == 0) c = uni(item_idx(last));
-      else c = uni(item_idx(H.load(0)));
+      else c = uni(item_idx(H.top[0]));    // the root always lives in LDS: no wait on the (global) load above
       if (order && !p.prof && lane == 0) order[npops] = c;
       ++npops;
       const int col = c / F;        // frame
