@@ -32,6 +32,7 @@ torch.cuda.synchronize()
 del m
 for B in sizes:
     m = mags(B)
+    d.pghi(m)                      # first touch of this size's workspace (tens of GB) is not part of the figure
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ph = d.pghi(m)
