@@ -180,11 +180,7 @@ __global__ __launch_bounds__(THREADS) void mel_gemm_kernel(MelParams p) {
   float* cur = buf0;
   float* nxt = buf1;
   for (; tile < tile_end; ++tile) {
-#ifdef AT_MEL_ABLATE
-    const bool has_next = false;
-#else
     const bool has_next = tile + 1 < tile_end;
-#endif
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const long long it = tile - (long long)blockIdx.x * p.tiles_per_block;
     int* flag_cur = flags + (int)(it % 3);
