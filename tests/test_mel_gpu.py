@@ -143,6 +143,9 @@ def test_default_bank_and_nmels(dev):
     mk = A.Magnitude(mode=None, keep_nyquist=False).to(dev)
     yk = mk(X)
     assert yk.shape[-1] == 512 and mk.invert(yk).shape[-1] == 513
+    fwd_k, inv_k = O.magnitude_banks(O.magnitude_default_bank(44100, 1024, keep_nyquist=False))
+    assert rel_max(cpu(yk), O.magnitude_forward(Xr, fwd_k, "log1p", keep_nyquist=False).numpy()) < TOL
+    assert rel_max(cpu(mk.invert(yk)), O.magnitude_invert(torch.from_numpy(cpu(yk)), inv_k, "log1p", keep_nyquist=False).numpy()) < TOL
 
 
 def test_mfcc_melspectrogram(dev):
