@@ -173,3 +173,10 @@ def test_offline_full_size_properties(dev):
     assert torch.equal(npops.cpu(), live.flatten(1).sum(1).cpu() + 0) or bool((npops.cpu() - live.flatten(1).sum(1).cpu()).abs().max() <= 1)
     assert bool((ph[~live] == 0).all())
     assert torch.equal(ph[0], ph[2])
+    # exact pop order at full size as well: here the heap outgrows its LDS share, so the global part of the
+    # array and the deep bubble rounds are on the checked path (the C oracle needs ~30 ms for such a clip)
+    _, npops1, order1 = ops.pghi_offline(mag[1:2], float(d.gamma), 1024, 256, float(d.tolerance), float(d.eps), debug=True)
+    r = O.pghi_offline(mag[1].cpu(), 1024, 256, want_order=True)
+    k = len(r["order"])
+    assert int(npops1[0]) == k
+    assert np.array_equal(order1[0][:k].cpu().numpy(), r["order"][:, 0] * 513 + r["order"][:, 1])
