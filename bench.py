@@ -343,9 +343,27 @@ def main():
         res["note"] = "angle+unwrap+finite difference(+Normalize) fused, one thread per (clip, bin) column"
         return res
 
+    def extra_mfcc40():
+        # BASELINE config 4's per-GPU work: audio -> log-mel (fused STFT kernel) -> DCT-II, 40 coefficients
+        mf = A.MFCC(sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS, n_mfcc=40).to(dev)
+        for _ in range(2):
+            mf(x)
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(5):
+            mf(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        return {"ms": round(ms, 4), "frames_per_s": frames_per_step / (ms * 1e-3),
+                "note": "MFCC(n_mfcc=40) forward, 1024 clips: fused STFT+log-mel kernel + DCT projection (extension: the "
+                        "reference's MFCC class has no DCT)"}
+
     if not args.no_extras:
         if rank == 0:
             guarded("phase_representations", extra_phase_repr)
+            guarded("mfcc40_forward", extra_mfcc40)
         if world > 1 and not rehearsal:
             guarded("with_feature_allgather_frames_per_s", extra_allgather)
         if rank == 0 and args.pghi_clips > 0:
