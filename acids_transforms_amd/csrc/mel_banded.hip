@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void small_proj_kernel(SmallProjParams p) {
   float cm[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cm[k] = 0.f;
-  long long run_t0 = (p.T > 0) ? r % p.T : 0;     // first frame of this wave's rows inside the current clip
+  long long cb = (p.T > 0) ? r / p.T : 0, ct = (p.T > 0) ? r - cb * p.T : 0;
+  long long run_t0 = ct;                          // first frame of this wave's rows inside the current clip
   const int k0 = 2 * lane;              // a row is K <= 128 floats: two per lane
   auto fetch = [&](long long row, float& a, float& b) {
     const float* src = p.x + row * p.K;
@@ -336,18 +337,23 @@ __global__ __launch_bounds__(256) void small_proj_kernel(SmallProjParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float acc = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four independent chains: one chain of K dependent fmas is latency-bound
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const float4 v = rowbuf[wave][q];            // same address on every lane: LDS broadcast
-      acc = fmaf(v.x, w[4 * q], acc);
-      acc = fmaf(v.y, w[4 * q + 1], acc);
-      acc = fmaf(v.z, w[4 * q + 2], acc);
-      acc = fmaf(v.w, w[4 * q + 3], acc);
+      a0 = fmaf(v.x, w[4 * q], a0);
+      a1 = fmaf(v.y, w[4 * q + 1], a1);
+      a2 = fmaf(v.z, w[4 * q + 2], a2);
+      a3 = fmaf(v.w, w[4 * q + 3], a3);
     }
+    float acc = (a0 + a1) + (a2 + a3);
     if (p.offset) acc = (acc - off) / sc;
     if (p.T > 0) {
-      const long long b = r / p.T, t = r - b * p.T;
+      const long long b = cb, t = ct;               // (clip, frame) of row r, tracked incrementally
+      if (++ct == p.T) {
+        ct = 0;
+        ++cb;
+      }
       if (t == 0) run_t0 = 0;
 #pragma unroll
       for (int k = 0; k < 7; ++k) cm[k] = cm[k + 1];
