@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
   clip_argmax(spec, n, abstol, 0.f, false, lane, max_val, max_pos);  // :173-174
   const float thr = max_val * p.tol;                                   // :177-178
   long long npops = 0;
-  long long c_pop1 = 0, c_bubble = 0, c_sift = 0, c_nb = 0, c_push = 0, n_push = 0;
+  long long c_pop1 = 0, c_bubble = 0, c_sift = 0, c_nb = 0, c_push = 0, n_push = 0, s_depth = 0, hn_max = 0;
 #define TICK() ((long long)__builtin_amdgcn_s_memtime())
   if (lane == 0) {
     H.store(0, pack_item(-max_val, (int)max_pos));  // :175
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
     while (hn > 0) {          // :180
       hn = uni(hn);
       const long long t0 = p.prof ? TICK() : 0;
+      if (p.prof) { s_depth += 31 - __clz((unsigned)hn | 1u); if (hn > hn_max) hn_max = hn; }
       // heappop, part 1: take the last entry off, read the root (heapq.py:51-56)
       const u64 last = H.load(hn - 1);     // usually deep in the global part: not needed before the leaf is known
       hn -= 1;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
   if (p.npops && lane == 0) p.npops[b] = npops;
   if (p.prof && order && lane == 0 && b == 0) {
     long long* o = reinterpret_cast<long long*>(order);
-    o[0] = npops; o[1] = c_pop1; o[2] = c_bubble; o[3] = c_sift; o[4] = c_nb; o[5] = c_push; o[6] = n_push;
+    o[0] = npops; o[1] = c_pop1; o[2] = c_bubble; o[3] = c_sift; o[4] = c_nb; o[5] = c_push; o[6] = n_push; o[7] = s_depth; o[8] = hn_max;
   }
 #undef TICK
 }

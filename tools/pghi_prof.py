@@ -11,10 +11,12 @@ x = torch.randn(B, 176400, device=dev) * 0.1
 m = d(x).abs()
 ph, npops, order = ops.pghi_offline(m, d._hostf("gamma"), 1024, 256, d._hostf("tolerance"), d._hostf("eps"), debug=True)
 torch.cuda.synchronize()
-o = order[0][:16].cpu().numpy().view("int64")
+o = order[0][:20].cpu().numpy().view("int64")
 n = o[0]
 names = ["pop1(load last/root, issue nb)", "bubble rounds", "final siftdown", "neighbour update", "pushes"]
 tot = sum(o[1:6])
 print("pops", n, "pushes", o[6], "ticks/pop total %.0f (s_memtime @100MHz => %.2f us)" % (tot / n, tot / n / 100.0))
 for i, nm in enumerate(names):
     print("  %-32s %7.1f ticks/pop  %4.1f%%" % (nm, o[1 + i] / n, 100.0 * o[1 + i] / tot))
+
+print("mean heap depth at pop %.2f levels, largest heap %d entries" % (o[7] / n, o[8]))
