@@ -19,10 +19,11 @@ from .transforms.oadd import OverlapAdd
 class StreamingDGTSession:
     def __init__(self, streams: int, chunk: int, n_fft: int = 1024, hop_length: int = 256, sr: int = 44100,
                  device="cuda", magnitude_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
-                 random_phase_below_tolerance: bool = True, use_graph: bool = True):
+                 random_phase_below_tolerance: bool = True, use_graph: bool = True, mel_bands: int = 0):
         """streams: concurrent streams S; chunk: samples per step (>= n_fft - hop).  `magnitude_fn`, if given,
         maps the (S, n, F) magnitudes to the magnitudes to resynthesise (a model working on |X|); it must
-        be capturable (device ops only)."""
+        be capturable (device ops only).  mel_bands > 0 also emits log1p mel features of every analysed frame
+        (`mel_out`, (S, n, mel_bands); banded projection of the spectrum, part of the captured graph)."""
         self.S, self.C, self.n_fft, self.hop = int(streams), int(chunk), int(n_fft), int(hop_length)
         dev = torch.device(device)
         self.device = dev
@@ -34,6 +35,11 @@ class StreamingDGTSession:
         self.gain = oa.gain_compensation.to(dev)
         self.magnitude_fn = magnitude_fn
         self.random_phase = random_phase_below_tolerance
+        self.mel = None
+        self.mel_out = None
+        if mel_bands:
+            from .transforms.spectral_repr import Magnitude
+            self.mel = Magnitude(sr=sr, n_fft=n_fft, n_mels=int(mel_bands), mode=None, contrast="log1p").to(dev)
         F = n_fft // 2 + 1
         # persistent streaming state (what OverlapAdd / RealtimeDGT keep as module buffers in the reference)
         self.x_in = torch.zeros(self.S, self.C, device=dev)
@@ -66,6 +72,11 @@ class StreamingDGTSession:
         X = ops.stft_forward(buf, self.dgt.window[:n], n, h, center=False, T=nw, clip_stride=buf.stride(0),
                              L=(nw - 1) * h + n, B=self.S)
         mag = ops.mag_pointwise(X)                                     # |X|
+        if self.mel is not None:
+            feat = self.mel(X)
+            if self.mel_out is None:
+                self.mel_out = torch.empty_like(feat)
+            self.mel_out.copy_(feat)
         if self.magnitude_fn is not None:
             mag = self.magnitude_fn(mag)
         noise = torch.randn_like(mag) if self.random_phase else torch.zeros_like(mag)

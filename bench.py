@@ -294,9 +294,11 @@ def main():
         from acids_transforms_amd.streaming import StreamingDGTSession
         S, C = args.streams, 1024
         chunk = torch.randn(S, C, device=dev, generator=gen) * 0.1
-        rtres = {"streams": S, "chunk_samples": C, "realtime_budget_ms": C / SR * 1e3}
+        rtres = {"streams": S, "chunk_samples": C, "realtime_budget_ms": C / SR * 1e3,
+                 "mel": "%d log1p mel features per analysed frame inside the step (fp32 banded projection; a bf16 "
+                        "bank would break the 1e-5 parity bar)" % N_MELS}
         for tag, use_graph in (("eager", False), ("hipgraph", True)):
-            sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=use_graph)
+            sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=use_graph, mel_bands=N_MELS)
             for _ in range(3):
                 sess.step(chunk)
             torch.cuda.synchronize()

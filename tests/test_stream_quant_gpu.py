@@ -103,8 +103,9 @@ def test_graph_captured_streaming_session_matches_modules(dev):
     S, C, n, h = 3, 1024, 1024, 256
     g = torch.Generator().manual_seed(21)
     x = torch.randn(S, 5 * C, generator=g) * 0.1
-    sess = StreamingDGTSession(S, C, n, h, device=dev, random_phase_below_tolerance=False, use_graph=True)
+    sess = StreamingDGTSession(S, C, n, h, device=dev, random_phase_below_tolerance=False, use_graph=True, mel_bands=128)
     assert sess.graph is not None
+    mel = A.Magnitude(n_fft=n, n_mels=128, mode=None, contrast="log1p").to(dev)
     oa, oi = A.OverlapAdd(n, h).to(dev), A.OverlapAdd(n, h).to(dev)
     rt = A.RealtimeDGT(n_fft=n, hop_length=h, batch_size=[S]).to(dev)
     for c in range(5):
@@ -119,5 +120,7 @@ def test_graph_captured_streaming_session_matches_modules(dev):
         yr = oi.invert(frames)
         assert y.shape == yr.shape == (S, C)
         assert rel_max(cpu(y), cpu(yr)) < 1e-5, c
+        assert sess.mel_out.shape == (S, C // h, 128)               # per-frame mel features ride in the same graph
+        assert rel_max(cpu(sess.mel_out), cpu(mel(rt(fr)))) < 1e-5, c
     # the resynthesis follows the input (PGHI keeps the magnitudes, re-estimates the phase)
     assert bool(torch.isfinite(y).all()) and float(y.abs().max()) > 1e-3
