@@ -31,49 +31,110 @@ constexpr int kFftLdsFloat2PerWave = 568;  // 7*72 + 63 + 1
 constexpr int kTwiddleCount = 22 * 64;
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
-// multiply by -i (forward) or +i (inverse)
-template <bool INV>
-__device__ __forceinline__ float2 mul_w4(float2 a) {
-  return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+// ---------------------------------------------------------------------------
+// Complex arithmetic on packed fp32 (v_pk_*_f32: one instruction, both components).  A complex number is a
+// 64-bit VGPR pair {re, im}.  The compiler folds operand *swaps* (op_sel) into packed instructions but not a
+// negation of one half only, and without that a complex multiply costs five instructions instead of two and
+// every multiplication by +-i an extra one (the auto-vectorised scalar version of this file: 372 VALU per
+// 1024-point frame, 119 of them moves).  The handful of operations that need a per-half sign are therefore
+// spelled as single instructions with explicit op_sel / neg modifiers:
+//   op_sel[i]    : half of source i that feeds the LOW result   (0 = low half)
+//   op_sel_hi[i] : half of source i that feeds the HIGH result  (1 = high half)
+//   neg_lo / neg_hi[i] : negate source i in the low / high result
+// ---------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f to_v(float2 a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ float2 to_f2(v2f a) { return make_float2(a.x, a.y); }
+
+// a + (-i) b = {a.x + b.y, a.y - b.x}
+__device__ __forceinline__ v2f add_mi(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-// multiply by W8 = (1 -/+ i)/sqrt2
-template <bool INV>
-__device__ __forceinline__ float2 mul_w8(float2 a) {
-  const float r = 0.70710678118654752440f;
-  return INV ? make_float2((a.x - a.y) * r, (a.x + a.y) * r) : make_float2((a.x + a.y) * r, (a.y - a.x) * r);
+// a + (+i) b = {a.x - b.y, a.y + b.x}
+__device__ __forceinline__ v2f add_pi(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-// multiply by W8^3 = (-1 -/+ i)/sqrt2
-template <bool INV>
-__device__ __forceinline__ float2 mul_w8_3(float2 a) {
-  const float r = 0.70710678118654752440f;
-  return INV ? make_float2((-a.x - a.y) * r, (a.x - a.y) * r) : make_float2((a.y - a.x) * r, (-a.x - a.y) * r);
+// a + r (-i) b = {a.x + r b.y, a.y - r b.x};  rr = {r, r} in scalar registers
+__device__ __forceinline__ v2f fma_mi(v2f a, v2f b, v2f rr) {
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(b), "s"(rr), "v"(a));
+  return r;
+}
+// a + r (+i) b = {a.x - r b.y, a.y + r b.x}
+__device__ __forceinline__ v2f fma_pi(v2f a, v2f b, v2f rr) {
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(b), "s"(rr), "v"(a));
+  return r;
+}
+// W4 = -i (forward) / +i (inverse):  a + W4 b,  a - W4 b,  a + r W4 b,  a - r W4 b
+template <bool INV> __device__ __forceinline__ v2f rot_add(v2f a, v2f b) { return INV ? add_pi(a, b) : add_mi(a, b); }
+template <bool INV> __device__ __forceinline__ v2f rot_sub(v2f a, v2f b) { return INV ? add_mi(a, b) : add_pi(a, b); }
+template <bool INV> __device__ __forceinline__ v2f rot_fma(v2f a, v2f b, v2f rr) { return INV ? fma_pi(a, b, rr) : fma_mi(a, b, rr); }
+template <bool INV> __device__ __forceinline__ v2f rot_fms(v2f a, v2f b, v2f rr) { return INV ? fma_mi(a, b, rr) : fma_pi(a, b, rr); }
+
+// a * w = {a.x w.x - a.y w.y, a.x w.y + a.y w.x}: two instructions
+__device__ __forceinline__ v2f cmul_v(v2f a, v2f w) {
+  const v2f t = a.yy * w.yx;   // {a.y w.y, a.y w.x}: a plain packed multiply with operand swaps
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+// a * conj(w) = {a.x w.x + a.y w.y, a.y w.x - a.x w.y}: the inverse transform uses the forward table as is
+__device__ __forceinline__ v2f cmul_conj_v(v2f a, v2f w) {
+  const v2f t = a.yy * w.yx;
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+template <bool INV> __device__ __forceinline__ v2f twiddle(v2f a, v2f w) { return INV ? cmul_conj_v(a, w) : cmul_v(a, w); }
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// h a + (-i) b = {h a.x + b.y, h a.y - b.x};  hh = {h, h} in scalar registers
+__device__ __forceinline__ v2f scale_add_mi(v2f a, v2f hh, v2f b) {
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "s"(hh), "v"(b));
+  return r;
 }
 
-// in-register 8-point DFT, natural-order output: v[k] = sum_n v[n] W8^{nk}
+// in-register 8-point DFT, natural-order output: v[k] = sum_n v[n] W8^{nk}.  26 packed instructions:
+// W8 = (1 + W4)/sqrt2 and W8^3 = (W4 - 1)/sqrt2, so the two odd rotations are one rotate-add each, their common
+// factor 1/sqrt2 rides on the last level's multiply-adds, and every multiplication by W4 is an operand swap.
 template <bool INV>
-__device__ __forceinline__ void radix8(float2 (&v)[8]) {
-  float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
-  float2 a1 = cadd(v[1], v[5]), a5 = mul_w8<INV>(csub(v[1], v[5]));
-  float2 a2 = cadd(v[2], v[6]), a6 = mul_w4<INV>(csub(v[2], v[6]));
-  float2 a3 = cadd(v[3], v[7]), a7 = mul_w8_3<INV>(csub(v[3], v[7]));
-  float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
-  float2 b1 = cadd(a1, a3), b3 = mul_w4<INV>(csub(a1, a3));
-  float2 b4 = cadd(a4, a6), b6 = csub(a4, a6);
-  float2 b5 = cadd(a5, a7), b7 = mul_w4<INV>(csub(a5, a7));
-  v[0] = cadd(b0, b1);
-  v[4] = csub(b0, b1);
-  v[2] = cadd(b2, b3);
-  v[6] = csub(b2, b3);
-  v[1] = cadd(b4, b5);
-  v[5] = csub(b4, b5);
-  v[3] = cadd(b6, b7);
-  v[7] = csub(b6, b7);
+__device__ __forceinline__ void radix8(v2f (&v)[8]) {
+  const v2f rr = {0.70710678118654752440f, 0.70710678118654752440f};
+  const v2f a0 = v[0] + v[4], a4 = v[0] - v[4];
+  const v2f a1 = v[1] + v[5], d1 = v[1] - v[5];
+  const v2f a2 = v[2] + v[6], d2 = v[2] - v[6];
+  const v2f a3 = v[3] + v[7], d3 = v[3] - v[7];
+  const v2f s5 = rot_add<INV>(d1, d1);        // sqrt2 W8 d1
+  const v2f s7 = rot_sub<INV>(d3, d3);        // -sqrt2 W8^3 d3
+  const v2f b0 = a0 + a2, b2 = a0 - a2;
+  const v2f b1 = a1 + a3, d13 = a1 - a3;
+  const v2f b4 = rot_add<INV>(a4, d2), b6 = rot_sub<INV>(a4, d2);
+  const v2f u5 = s5 - s7, u7 = s5 + s7;       // sqrt2 (a5 + a7), sqrt2 (a5 - a7)
+  v[0] = b0 + b1;
+  v[4] = b0 - b1;
+  v[2] = rot_add<INV>(b2, d13);
+  v[6] = rot_sub<INV>(b2, d13);
+  v[1] = __builtin_elementwise_fma(u5, rr, b4);
+  v[5] = __builtin_elementwise_fma(-u5, rr, b4);
+  v[3] = rot_fma<INV>(b6, u7, rr);
+  v[7] = rot_fms<INV>(b6, u7, rr);
 }
 
 // compiler-level ordering of this wave's LDS traffic (the hardware already
@@ -84,54 +145,58 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Twiddles are stored with the forward sign in every kernel (the inverse multiplies by the conjugate in the
+// same two instructions).  `tr` holds W1024^k / 2 in forward kernels (the real-FFT merge wants the half) and
+// W1024^k in inverse ones: `TR_SCALE`.
 // twiddles held in registers (loop invariant, 44 VGPRs) ...
 struct Twiddles {
-  float2 t1[7];
-  float2 t2[7];
-  float2 tr[8];
-  __device__ __forceinline__ float2 get1(int k) const { return t1[k]; }
-  __device__ __forceinline__ float2 get2(int k) const { return t2[k]; }
-  __device__ __forceinline__ float2 getr(int m) const { return tr[m]; }
+  v2f t1[7];
+  v2f t2[7];
+  v2f tr[8];
+  __device__ __forceinline__ v2f get1(int k) const { return t1[k]; }
+  __device__ __forceinline__ v2f get2(int k) const { return t2[k]; }
+  __device__ __forceinline__ v2f getr(int m) const { return tr[m]; }
 };
 
 // ... or read at the point of use from a workgroup-shared LDS copy of the table
 // (tab[row * 64 + lane]: consecutive lanes, conflict-free ds_read_b64), trading 22 LDS reads per
-// frame for 44 VGPRs -- one more resident wave per SIMD in the streaming kernels.
+// frame for 44 VGPRs -- one more resident wave per SIMD in the streaming kernels.  The kernel that fills
+// the LDS copy applies the forward 1/2 to rows 14..21 (`twiddle_for_lds`).
 template <bool INV>
 struct LdsTwiddles {
-  const float2* tab;  // kTwiddleCount float2 in LDS, forward-sign values
+  const float2* tab;  // kTwiddleCount float2 in LDS
   int lane;
-  __device__ __forceinline__ float2 fix(float2 a) const { return INV ? make_float2(a.x, -a.y) : a; }
-  __device__ __forceinline__ float2 get1(int k) const { return fix(tab[k * 64 + lane]); }
-  __device__ __forceinline__ float2 get2(int k) const { return fix(tab[(7 + k) * 64 + lane]); }
-  __device__ __forceinline__ float2 getr(int m) const { return fix(tab[(14 + m) * 64 + lane]); }
+  __device__ __forceinline__ v2f get1(int k) const { return reinterpret_cast<const v2f*>(tab)[k * 64 + lane]; }
+  __device__ __forceinline__ v2f get2(int k) const { return reinterpret_cast<const v2f*>(tab)[(7 + k) * 64 + lane]; }
+  __device__ __forceinline__ v2f getr(int m) const { return reinterpret_cast<const v2f*>(tab)[(14 + m) * 64 + lane]; }
 };
+template <bool INV>
+__device__ __forceinline__ float2 twiddle_for_lds(const float2* __restrict__ tab, int i) {
+  const float2 a = tab[i];
+  return (!INV && i >= 14 * 64) ? make_float2(0.5f * a.x, 0.5f * a.y) : a;
+}
 
 template <bool INV>
 __device__ __forceinline__ void load_twiddles(Twiddles& tw, const float2* __restrict__ tab, int lane) {
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
-    float2 a = tab[k * 64 + lane];
-    float2 b = tab[(7 + k) * 64 + lane];
-    tw.t1[k] = INV ? cconj(a) : a;
-    tw.t2[k] = INV ? cconj(b) : b;
+    tw.t1[k] = to_v(tab[k * 64 + lane]);
+    tw.t2[k] = to_v(tab[(7 + k) * 64 + lane]);
   }
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    float2 c = tab[(14 + m) * 64 + lane];
-    tw.tr[m] = INV ? cconj(c) : c;
-  }
+  for (int m = 0; m < 8; ++m) tw.tr[m] = to_v(twiddle_for_lds<INV>(tab, (14 + m) * 64 + lane));
 }
 
 // 512-point complex FFT of one wave.  In: v[m] = z[lane + 64 m].
 // Out: v[m] = Z[lane + 64 m] (unnormalised).  `lds` is this wave's private slab
 // of kFftLdsFloat2PerWave float2.
 template <bool INV, typename TW>
-__device__ __forceinline__ void fft512(float2 (&v)[8], const TW& tw, float2* lds, int lane) {
+__device__ __forceinline__ void fft512(v2f (&v)[8], const TW& tw, float2* lds_f2, int lane) {
+  v2f* lds = reinterpret_cast<v2f*>(lds_f2);
   const int lo = lane & 7, hi = lane >> 3;
   radix8<INV>(v);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.get1(k - 1));
+  for (int k = 1; k < 8; ++k) v[k] = twiddle<INV>(v[k], tw.get1(k - 1));
   // xchg 1: writer (n0=lo, n1=hi), element k0 -> index n1*72 + n0 + 8*k0
 #pragma unroll
   for (int k = 0; k < 8; ++k) lds[hi * 72 + lo + 8 * k] = v[k];
@@ -141,7 +206,7 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], const TW& tw, float2* lds
   wave_lds_sync();
   radix8<INV>(v);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw.get2(k - 1));
+  for (int k = 1; k < 8; ++k) v[k] = twiddle<INV>(v[k], tw.get2(k - 1));
   // xchg 2: writer (n0=lo, k0=hi), element k1 -> index n0*66 + k0 + 8*k1
 #pragma unroll
   for (int k = 0; k < 8; ++k) lds[lo * 66 + hi + 8 * k] = v[k];
@@ -151,11 +216,20 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], const TW& tw, float2* lds
   wave_lds_sync();
   radix8<INV>(v);
 }
+template <bool INV, typename TW>
+__device__ __forceinline__ void fft512(float2 (&f)[8], const TW& tw, float2* lds, int lane) {
+  v2f v[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = to_v(f[m]);
+  fft512<INV>(v, tw, lds, lane);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) f[m] = to_f2(v[m]);
+}
 
 // Fetch the mirror partner P[m] = Z[(512 - (lane + 64 m)) mod 512] of every element.
-__device__ __forceinline__ void mirror512(const float2 (&v)[8], float2 (&p)[8], int lane) {
+__device__ __forceinline__ void mirror512(const v2f (&v)[8], v2f (&p)[8], int lane) {
   const int src = (64 - lane) & 63;
-  float2 q[8];
+  v2f q[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     q[m].x = __shfl(v[m].x, src, 64);
@@ -165,50 +239,64 @@ __device__ __forceinline__ void mirror512(const float2 (&v)[8], float2 (&p)[8], 
   // lane>0: partner lives in lane 64-lane, register 7-m
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    float2 a = q[7 - m];
-    float2 b = q[(8 - m) & 7];
+    const v2f a = q[7 - m];
+    const v2f b = q[(8 - m) & 7];
     p[m] = (lane == 0) ? b : a;
   }
 }
 
 // real-FFT merge after the forward complex FFT:
 //   X[k] = (Z[k] + conj Z[512-k])/2 - (i/2) W1024^k (Z[k] - conj Z[512-k]),  k = lane + 64 m
-// returns X[512] (Nyquist) in `nyq` (meaningful on lane 0 only).
+// returns X[512] (Nyquist) in `nyq` (meaningful on lane 0 only).  `tw.getr` = W1024^k / 2 (forward tables).
 template <typename TW>
-__device__ __forceinline__ void rfft_merge(float2 (&v)[8], const TW& tw, int lane, float2& nyq) {
-  float2 p[8];
+__device__ __forceinline__ void rfft_merge(v2f (&v)[8], const TW& tw, int lane, float2& nyq) {
+  const v2f hh = {0.5f, 0.5f};
+  v2f p[8];
   mirror512(v, p, lane);
   nyq = make_float2(v[0].x - v[0].y, 0.0f);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    float2 zp = cconj(p[m]);
-    float2 e = make_float2(0.5f * (v[m].x + zp.x), 0.5f * (v[m].y + zp.y));
-    float2 d = make_float2(0.5f * (v[m].x - zp.x), 0.5f * (v[m].y - zp.y));
-    float2 wd = cmul(tw.getr(m), d);  // W^k * d
-    // -i * wd = (wd.y, -wd.x)
-    v[m] = make_float2(e.x + wd.y, e.y - wd.x);
+    const v2f e = add_conj(v[m], p[m]);              // Z + conj Z'
+    const v2f d = sub_conj(v[m], p[m]);              // Z - conj Z'
+    const v2f wd = cmul_v(d, tw.getr(m));            // (W/2) d
+    v[m] = scale_add_mi(e, hh, wd);                  // e/2 - i wd
   }
+}
+template <typename TW>
+__device__ __forceinline__ void rfft_merge(float2 (&f)[8], const TW& tw, int lane, float2& nyq) {
+  v2f v[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = to_v(f[m]);
+  rfft_merge(v, tw, lane, nyq);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) f[m] = to_f2(v[m]);
 }
 
 // inverse of rfft_merge: from one-sided X (X[512] passed as xnyq_re to lane 0)
 // build Z[k] = E[k] + i O[k] with E = (X[k] + conj X[512-k]), O = (X[k] - conj X[512-k]) conj(W1024^k)
-// (the common factor 1/2 is folded into the caller's 1/N scale).
-// `tw` must have been loaded with INV = true (tr = conj W1024^k).
+// (the common factor 1/2 is folded into the caller's 1/N scale).  `tw.getr` = W1024^k (inverse tables).
 template <typename TW>
-__device__ __forceinline__ void irfft_split(float2 (&v)[8], const TW& tw, int lane, float xnyq_re) {
+__device__ __forceinline__ void irfft_split(v2f (&v)[8], const TW& tw, int lane, float xnyq_re) {
   // c2r ignores the imaginary parts of DC and Nyquist
   if (lane == 0) v[0].y = 0.0f;
-  float2 p[8];
+  v2f p[8];
   mirror512(v, p, lane);
-  if (lane == 0) p[0] = make_float2(xnyq_re, 0.0f);  // partner of k=0 is X[512]
+  if (lane == 0) p[0] = (v2f){xnyq_re, 0.0f};  // partner of k=0 is X[512]
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    float2 xp = cconj(p[m]);
-    float2 e = cadd(v[m], xp);
-    float2 d = cmul(csub(v[m], xp), tw.getr(m));
-    // Z = e + i d
-    v[m] = make_float2(e.x - d.y, e.y + d.x);
+    const v2f e = add_conj(v[m], p[m]);
+    const v2f d = cmul_conj_v(sub_conj(v[m], p[m]), tw.getr(m));
+    v[m] = add_pi(e, d);                              // Z = e + i d
   }
+}
+template <typename TW>
+__device__ __forceinline__ void irfft_split(float2 (&f)[8], const TW& tw, int lane, float xnyq_re) {
+  v2f v[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = to_v(f[m]);
+  irfft_split(v, tw, lane, xnyq_re);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) f[m] = to_f2(v[m]);
 }
 
 }  // namespace at_hip

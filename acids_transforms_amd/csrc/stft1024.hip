@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
   float2* tab = lds_all + FWD_WAVES * kFftLdsFloat2PerWave;
   // workgroup-shared constants: (twiddle table,) analysis window, band weights
   if (TWLDS)
-    for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * FWD_WAVES) tab[i] = p.tw[i];
+    for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * FWD_WAVES) tab[i] = twiddle_for_lds<false>(p.tw, i);
   for (int i = threadIdx.x; i < 512; i += 64 * FWD_WAVES)
     tab[kTabTw + i] = reinterpret_cast<const float2*>(p.window)[i];
   float* wlds = reinterpret_cast<float*>(band_lds);
@@ -303,12 +303,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
     raw[6] = n6;
     raw[7] = n7;
     float2 nyq;
-    if (TWLDS) {
-      fft512<false>(v, tw_lds, lds, lane);
-      rfft_merge(v, tw_lds, lane, nyq);
-    } else {
-      fft512<false>(v, tw_regs, lds, lane);
-      rfft_merge(v, tw_regs, lane, nyq);
+    {
+      v2f z[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) z[m] = to_v(v[m]);
+      if (TWLDS) {
+        fft512<false>(z, tw_lds, lds, lane);
+        rfft_merge(z, tw_lds, lane, nyq);
+      } else {
+        fft512<false>(z, tw_regs, lds, lane);
+        rfft_merge(z, tw_regs, lane, nyq);
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = to_f2(z[m]);
     }
     if (MEL != 2) {
 #pragma unroll
@@ -531,17 +538,25 @@ __device__ __forceinline__ void load_spectrum(const InvParams& p, long long f, i
   raw_to_spectrum(q, v, nyq_re);
 }
 
+// the synthesis window with the transform's 1/N folded in (a power of two: the products round the same)
+__device__ __forceinline__ float2 scaled_window(const float* window, int i) {
+  const float2 w = reinterpret_cast<const float2*>(window)[i];
+  return make_float2(w.x * (1.0f / 1024.0f), w.y * (1.0f / 1024.0f));
+}
+
 // one frame: spectrum -> windowed time samples y[m] = (x[2n], x[2n+1]) * w, n = lane + 64 m
 template <typename TW>
 __device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const TW& tw, const float2* win,
                                             float2* lds, int lane) {
-  irfft_split(v, tw, lane, nyq_re);
-  fft512<true>(v, tw, lds, lane);
-  const float s = 1.0f / 1024.0f;
+  v2f z[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) z[m] = to_v(v[m]);
+  irfft_split(z, tw, lane, nyq_re);
+  fft512<true>(z, tw, lds, lane);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    const float2 w = win[lane + 64 * m];   // synthesis window, workgroup-shared LDS copy
-    v[m] = make_float2((v[m].x * s) * w.x, (v[m].y * s) * w.y);
+    const v2f w = reinterpret_cast<const v2f*>(win)[lane + 64 * m];   // window / 1024, workgroup-shared LDS copy
+    v[m] = to_f2(z[m] * w);
   }
 }
 
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* win = lds_all + WAVES_PER_BLOCK * kFftLdsFloat2PerWave;
   float2* twtab = win + 512;
-  for (int i = threadIdx.x; i < 512; i += 64 * WAVES_PER_BLOCK) win[i] = reinterpret_cast<const float2*>(p.window)[i];
+  for (int i = threadIdx.x; i < 512; i += 64 * WAVES_PER_BLOCK) win[i] = scaled_window(p.window, i);
   if (TWLDS)
     for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * WAVES_PER_BLOCK) twtab[i] = p.tw[i];
   __syncthreads();
@@ -693,7 +708,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void irfft1024_frames_kernel(
   const int wave = threadIdx.x >> 6;
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* win = lds_all + WAVES_PER_BLOCK * kFftLdsFloat2PerWave;
-  for (int i = threadIdx.x; i < 512; i += 64 * WAVES_PER_BLOCK) win[i] = reinterpret_cast<const float2*>(p.window)[i];
+  for (int i = threadIdx.x; i < 512; i += 64 * WAVES_PER_BLOCK) win[i] = scaled_window(p.window, i);
   __syncthreads();
   Twiddles tw;
   load_twiddles<true>(tw, p.tw, lane);
