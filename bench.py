@@ -362,8 +362,35 @@ def main():
                 "note": "MFCC(n_mfcc=40) forward, 1024 clips: fused STFT+log-mel kernel + DCT projection (extension: the "
                         "reference's MFCC class has no DCT)"}
 
+    def extra_hbm_probe():
+        # what this box's HBM gives a flat streaming kernel today (a measured ceiling next to the spec)
+        n = 1 << 29                                   # 2 GiB of fp32
+        a = torch.empty(n, device=dev)
+        b = torch.empty(n, device=dev)
+
+        def timed(fn, reps=6):
+            fn()
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e-3
+
+        t_fill = timed(lambda: a.fill_(1.0))
+        t_copy = timed(lambda: b.copy_(a))
+        t_read = timed(lambda: a.sum())
+        return {"copy_GBps": round(2 * 4 * n / t_copy / 1e9, 1), "fill_GBps": round(4 * n / t_fill / 1e9, 1),
+                "read_sum_GBps": round(4 * n / t_read / 1e9, 1),
+                "note": "torch fill_/copy_/sum on 2 GiB fp32 buffers: the practical ceiling for the fractions above "
+                        "(roofline.peak stays the 8 TB/s spec)"}
+
     if not args.no_extras:
         if rank == 0:
+            guarded("hbm_probe", extra_hbm_probe)
             guarded("phase_representations", extra_phase_repr)
             guarded("mfcc40_forward", extra_mfcc40)
         if world > 1 and not rehearsal:
