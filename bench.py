@@ -207,7 +207,17 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         avg["mel"] = e0.elapsed_time(e1) / 5
+        # the framing pass on its own (STFT.forward without the fused epilogue), also outside the step
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(5):
+            Xs = stft(x)
+        e1.record()
+        torch.cuda.synchronize()
+        avg["stft_fwd_plain"] = e0.elapsed_time(e1) / 5
         del Xs
+        kernels.append(hbm_entry("stft_fwd_plain", BYTES_STFT_FWD))
+        kernels[-1]["kernel"] = "stft_fwd (framing + FFT only, outside the step)"
     else:
         kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD), hbm_entry("istft", BYTES_ISTFT)]
     kernels.append(hbm_entry("mel", BYTES_MEL))
