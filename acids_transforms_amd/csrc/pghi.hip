@@ -305,6 +305,15 @@ struct Heap {
     if (pos < cap) top[pos] = v;
     else gstore(rest + pos, v);
   }
+  // entry `pos` for the lanes that `want` it, `dflt` for the others.  The LDS read is unconditional (slot 0 for
+  // lanes that do not want it or whose entry is global): one divergent region -- the global load -- instead of
+  // a nest of three, and none at all while the whole subtree is in LDS.
+  __device__ __forceinline__ u64 load_if(int pos, bool want, u64 dflt) const {
+    const bool in_lds = pos < cap;
+    u64 v = top[(want && in_lds) ? pos : 0];
+    if (want && !in_lds) v = gload(rest + pos);
+    return want ? v : dflt;
+  }
 };
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
   const unsigned lo = __shfl((unsigned)v, src, 64);
@@ -346,16 +355,29 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
 
 // utils/heapq.py:51-59 (+ :24-42): the bubble-up part of heappop after `last` was taken off the end
 // (n = remaining size >= 1).  Returns the leaf position where `last` has to be placed.
-__device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64& leaf_old) {
+// lanes {L, L >> 1, L >> 2, ...} >= 2: the nodes that must all be chosen children for local node L to bubble up
+__device__ __forceinline__ u64 chain_mask(int lane) {
+  u64 m = 0;
+  for (int a = lane; a >= 2; a >>= 1) m |= 1ull << a;
+  return m;
+}
+
+__device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64 anc_mask, u64& leaf_old) {
   int pos = 0;  // the hole
   const int lvl = 31 - __clz((unsigned)lane | 1u);
   const int off = lane - (1 << lvl);
   const u64 kInf = (u64)0x7f800000u << 32;
+  // Rounds are aligned to the *bottom* of the heap: the first one descends only ((D - 1) mod 5) + 1 levels
+  // (D = the last level), so that the last round covers levels D-4 .. D.  With the top 12 levels in LDS a heap
+  // of up to 2^17 entries then pays one global round per pop, where top-aligned rounds (1-5, 6-10, 11-15, 16)
+  // pay two as soon as D = 16 -- a third of all pops on dense spectra.  Same number of rounds either way.
+  const int last_level = 31 - __clz((unsigned)n | 1u);
+  int limit = last_level >= 1 ? ((last_level - 1) % 5) + 1 : 5;
   for (;;) {
     // subtree under the hole: local node `lane` (1..63) <-> global index g
     const long long g = (((long long)pos + 1) << lvl) - 1 + off;
-    const bool valid = (lane >= 1) && (g < (long long)n);
-    const u64 val = valid ? H.load(g) : kInf;
+    const bool valid = (lane >= 1) && (lvl <= limit) && (g < (long long)n);
+    const u64 val = H.load_if((int)g, valid, kInf);
     const float key = item_key(val);
     // "am I the child my parent bubbles up?"  children 2i (left, even lane) and 2i+1 (right, odd lane) are
     // DPP neighbours.  heapq.py:33: take the right child iff it exists and not (left < right).
@@ -366,33 +388,21 @@ __device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64& 
     const bool chosen = valid && (is_right ? right_wins : !right_wins);
     const u64 W = __ballot(chosen && lane >= 2);
     // The chain of bubbled-up nodes below the subtree root: node L belongs to it iff L and every ancestor of
-    // L down to level 1 is its parent's chosen child.  Each lane tests its own <= 5 bits of W (a serial walk
-    // from the root costs five dependent scalar steps per round); below a leaf no bit is set, so the chain
-    // simply ends there.
-    bool on_chain = (lane >= 2) && ((W >> lane) & 1ull);
-    {
-      int a = lane >> 1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (a >= 2) on_chain = on_chain && ((W >> a) & 1ull);
-        a >>= 1;
-      }
-    }
+    // L down to level 1 is its parent's chosen child, i.e. iff W covers the lane's ancestor mask; below a
+    // leaf no bit is set, so the chain simply ends there.
+    const bool on_chain = (lane >= 2) && ((W & anc_mask) == anc_mask);
     const u64 chain = __ballot(on_chain);
     const int steps = __builtin_popcountll(chain);
     const int cur = steps ? 63 - __builtin_clzll(chain) : 1;          // the final hole of this round
-    const u64 pathmask = steps ? ((chain & ~(1ull << cur)) | 2ull) : 0ull;   // nodes that receive their chosen child
-    // every inner lane knows its chosen child from W; the path nodes fetch that child's entry and store it
-    const int cl = (2 * lane) & 63;
-    const int nx = ((W >> cl) & 1ull) ? cl : cl + 1;
-    const u64 moved = shfl64(val, nx);
-    if ((pathmask >> lane) & 1ull) H.store(g, moved);
+    // every bubbled-up entry moves into its parent's slot (the hole, or the chain node above it)
+    if (on_chain) H.store((g - 1) >> 1, val);
     const int gcur = __builtin_amdgcn_readlane((int)g, cur);
     pos = gcur;
-    if (steps < 5 || 2LL * gcur + 1 >= (long long)n) {
+    if (steps < limit || 2LL * gcur + 1 >= (long long)n) {
       leaf_old = readlane64(val, cur);   // what the final hole held: now the value of its parent
       break;
     }
+    limit = 5;
   }
   return pos;
 }
@@ -409,6 +419,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
   float* phase = p.phase + b * n;
   extern __shared__ __attribute__((aligned(16))) u64 heap_top[];
   const Heap H = {heap_top, reinterpret_cast<u64*>(p.heap + b * (n + 2)), p.heap_lds_cap};
+  const u64 anc_mask = chain_mask(lane);
   int* order = p.order ? p.order + b * n : nullptr;
   const float abstol = p.abstol;
 
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
       long long t2 = t1;
       if (hn > 0) {
         u64 leaf_old = 0;
-        const int leaf = coop_bubble(H, hn, lane, leaf_old);
+        const int leaf = coop_bubble(H, hn, lane, anc_mask, leaf_old);
         t2 = p.prof ? TICK() : 0;
         // `last` goes into the leaf and rises while it is smaller than its parent (heapq.py:39-42).  The
         // parent of the leaf now holds the entry that just left the leaf, which is still in registers: in
@@ -819,6 +830,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
   float* tg1 = tg0 + F;
   float* fg1 = tg1 + F;        // padded fgradw row f
   const Heap H = {reinterpret_cast<u64*>(fg1 + F + (F & 1)), nullptr, 0x7fffffff};
+  const u64 anc_mask = chain_mask(lane);
   auto lds_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -888,7 +900,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
           const float s_dn = srow[k >= 1 ? k - 1 : 0];
           if (hn > 0) {
             u64 leaf_old = 0;
-            const int leaf = coop_bubble(H, hn, lane, leaf_old);
+            const int leaf = coop_bubble(H, hn, lane, anc_mask, leaf_old);
             if (leaf == 0 || !(item_key(last) < item_key(leaf_old))) {
               if (lane == 0) H.store(leaf, last);
             } else {
@@ -1048,7 +1060,9 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
       cus = prop.multiProcessorCount;
   }
   const long long per_cu = (B + cus - 1) / cus;
-  const int cap = per_cu <= 4 ? 4095 : per_cu <= 8 ? 2047 : per_cu <= 16 ? 1023 : 511;
+  int cap = per_cu <= 4 ? 4095 : per_cu <= 8 ? 2047 : per_cu <= 16 ? 1023 : 511;
+  if (getenv("ACIDS_XCAP")) cap = atoi(getenv("ACIDS_XCAP"));   // EXPERIMENT
+  if (cap > 8000) (void)hipFuncSetAttribute((const void*)pghi_hgi_offline_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(u64) * (size_t)(cap + 1)));   // EXPERIMENT
   HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, cap, prof, order_or_null};
   // ACIDS_PGHI_SERIAL=1 selects the single-lane reference kernel (debugging aid; identical results)
   static const bool serial = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
