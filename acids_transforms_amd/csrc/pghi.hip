@@ -332,8 +332,7 @@ __device__ __forceinline__ void coop_siftdown(const Heap& H, int pos, u64 item, 
   const int sh = lane < 31 ? lane : 30;           // lanes >= depth are idle; keep their shifts defined
   const int my_dst = (int)(q >> sh) - 1;          // lane L: position of ancestor L-1 (L = 0: pos itself)
   const int my_anc = (int)(q >> (sh + 1)) - 1;    // lane L: position of ancestor L
-  u64 anc = 0;
-  if (lane < depth) anc = H.load(my_anc);
+  const u64 anc = H.load_if(my_anc, lane < depth, 0);
   const bool rises = (lane < depth) && (item_key(item) < item_key(anc));
   const u64 mask = __ballot(rises);
   const int m = (mask == ~0ull) ? 64 : __builtin_ctzll(~mask);  // item passes ancestors 0 .. m-1
@@ -375,17 +374,17 @@ __device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64 a
   int limit = last_level >= 1 ? ((last_level - 1) % 5) + 1 : 5;
   for (;;) {
     // subtree under the hole: local node `lane` (1..63) <-> global index g
-    const long long g = (((long long)pos + 1) << lvl) - 1 + off;
-    const bool valid = (lane >= 1) && (lvl <= limit) && (g < (long long)n);
-    const u64 val = H.load_if((int)g, valid, kInf);
+    const int g = ((pos + 1) << lvl) - 1 + off;           // < 2^25: heap positions are < T F < 2^31 >> 5
+    const bool valid = (lane >= 1) && (lvl <= limit) && (g < n);
+    const u64 val = H.load_if(g, valid, kInf);
     const float key = item_key(val);
     // "am I the child my parent bubbles up?"  children 2i (left, even lane) and 2i+1 (right, odd lane) are
-    // DPP neighbours.  heapq.py:33: take the right child iff it exists and not (left < right).
+    // DPP neighbours.  heapq.py:33: take the right child iff it exists and not (left < right); a missing child
+    // reads as +inf (real keys are -magnitude, finite), so one compare `left < right` decides for both lanes.
     const float sib = dpp_xor1(key);
-    const int sib_valid = dpp_xor1_i((int)valid);
     const bool is_right = lane & 1;
-    const bool right_wins = is_right ? (valid && !(sib < key)) : (sib_valid && !(key < sib));
-    const bool chosen = valid && (is_right ? right_wins : !right_wins);
+    const bool left_lt_right = is_right ? (sib < key) : (key < sib);
+    const bool chosen = valid && (left_lt_right != is_right);
     const u64 W = __ballot(chosen && lane >= 2);
     // The chain of bubbled-up nodes below the subtree root: node L belongs to it iff L and every ancestor of
     // L down to level 1 is its parent's chosen child, i.e. iff W covers the lane's ancestor mask; below a
@@ -396,9 +395,9 @@ __device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64 a
     const int cur = steps ? 63 - __builtin_clzll(chain) : 1;          // the final hole of this round
     // every bubbled-up entry moves into its parent's slot (the hole, or the chain node above it)
     if (on_chain) H.store((g - 1) >> 1, val);
-    const int gcur = __builtin_amdgcn_readlane((int)g, cur);
+    const int gcur = __builtin_amdgcn_readlane(g, cur);
     pos = gcur;
-    if (steps < limit || 2LL * gcur + 1 >= (long long)n) {
+    if (steps < limit || 2 * gcur + 1 >= n) {
       leaf_old = readlane64(val, cur);   // what the final hole held: now the value of its parent
       break;
     }
@@ -407,6 +406,7 @@ __device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64 a
   return pos;
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) {
   const long long b = blockIdx.x;
   if (b >= p.B) return;
@@ -422,6 +422,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
   const u64 anc_mask = chain_mask(lane);
   int* order = p.order ? p.order + b * n : nullptr;
   const float abstol = p.abstol;
+  const float inv_F = 1.0f / (float)F;
 
   for (long long i = lane; i < n; i += 64) phase[i] = 0.0f;  // dgt.py:170
 
@@ -442,18 +443,22 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
   while (max_val > abstol) {  // :179
     while (hn > 0) {          // :180
       hn = uni(hn);
-      const long long t0 = p.prof ? TICK() : 0;
-      if (p.prof) { s_depth += 31 - __clz((unsigned)hn | 1u); if (hn > hn_max) hn_max = hn; }
+      const long long t0 = PROF ? TICK() : 0;
+      if (PROF) { s_depth += 31 - __clz((unsigned)hn | 1u); if (hn > hn_max) hn_max = hn; }
       // heappop, part 1: take the last entry off, read the root (heapq.py:51-56)
       const u64 last = H.load(hn - 1);     // usually deep in the global part: not needed before the leaf is known
       hn -= 1;
       int c;
       if (hn == 0) c = uni(item_idx(last));
       else c = uni(item_idx(H.top[0]));    // the root always lives in LDS: no wait on the (global) load above
-      if (order && !p.prof && lane == 0) order[npops] = c;
+      if (order && !PROF && lane == 0) order[npops] = c;
       ++npops;
-      const int col = c / F;        // frame
-      const int row = c - col * F;  // bin
+      // frame / bin of c without an integer division (~25 dependent instructions on the pop's critical path):
+      // float quotient, exact after one correction either way
+      int col = (int)((float)c * inv_F);
+      int row = c - col * F;
+      if (row < 0) { row += F; col -= 1; }
+      else if (row >= F) { row -= F; col += 1; }
       // request the neighbourhood now (lanes 0..3: next frame, previous frame, next bin, previous bin,
       // dgt.py:188-215); it does not depend on the heap repair below and arrives while that runs
       const int d = (lane == 0) ? F : (lane == 1) ? -F : (lane == 2) ? 1 : -1;
@@ -468,13 +473,13 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
         g_n = gr[nb];
         pc = fload(phase + c);
       }
-      const long long t1 = p.prof ? TICK() : 0;
+      const long long t1 = PROF ? TICK() : 0;
       // heappop, part 2: bubble the smaller children up, drop `last` into the leaf, let it rise
       long long t2 = t1;
       if (hn > 0) {
         u64 leaf_old = 0;
         const int leaf = coop_bubble(H, hn, lane, anc_mask, leaf_old);
-        t2 = p.prof ? TICK() : 0;
+        t2 = PROF ? TICK() : 0;
         // `last` goes into the leaf and rises while it is smaller than its parent (heapq.py:39-42).  The
         // parent of the leaf now holds the entry that just left the leaf, which is still in registers: in
         // the common case (`last` does not rise at all) no ancestor has to be read back.
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
           coop_siftdown(H, leaf, last, lane);
         }
       }
-      const long long t3 = p.prof ? TICK() : 0;
+      const long long t3 = PROF ? TICK() : 0;
       const bool lv = (lane < 4) && inb && live(s, abstol, thr);
       if (lv) {
         const int nb = c + d;
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
         spec[nb] = abstol;
       }
       const u64 lvmask = __ballot(lv);
-      const long long t4 = p.prof ? TICK() : 0;
+      const long long t4 = PROF ? TICK() : 0;
       const u64 mine = pack_item(-s, c + d);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
           ++n_push;
         }
       }
-      if (p.prof) {
+      if (PROF) {
         const long long t5 = TICK();
         c_pop1 += t1 - t0; c_bubble += t2 - t1; c_sift += t3 - t2; c_nb += t4 - t3; c_push += t5 - t4;
       }
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
   if (p.npops && lane == 0) p.npops[b] = npops;
-  if (p.prof && order && lane == 0 && b == 0) {
+  if (PROF && order && lane == 0 && b == 0) {
     long long* o = reinterpret_cast<long long*>(order);
     o[0] = npops; o[1] = c_pop1; o[2] = c_bubble; o[3] = c_sift; o[4] = c_nb; o[5] = c_push; o[6] = n_push; o[7] = s_depth; o[8] = hn_max;
   }
@@ -1060,16 +1065,20 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
       cus = prop.multiProcessorCount;
   }
   const long long per_cu = (B + cus - 1) / cus;
-  int cap = per_cu <= 4 ? 4095 : per_cu <= 8 ? 2047 : per_cu <= 16 ? 1023 : 511;
-  if (getenv("ACIDS_XCAP")) cap = atoi(getenv("ACIDS_XCAP"));   // EXPERIMENT
-  if (cap > 8000) (void)hipFuncSetAttribute((const void*)pghi_hgi_offline_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(u64) * (size_t)(cap + 1)));   // EXPERIMENT
+  const int cap = per_cu <= 1 ? 16383 : per_cu <= 2 ? 8191 : per_cu <= 4 ? 4095 : per_cu <= 8 ? 2047 : per_cu <= 16 ? 1023 : 511;
+  const size_t heap_lds = sizeof(u64) * (size_t)(cap + 1);
   HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, cap, prof, order_or_null};
   // ACIDS_PGHI_SERIAL=1 selects the single-lane reference kernel (debugging aid; identical results)
   static const bool serial = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
-  if (serial)
+  if (serial) {
     hipLaunchKernelGGL(pghi_hgi_offline_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
-  else
-    hipLaunchKernelGGL(pghi_hgi_offline_coop_kernel, dim3((unsigned)B), dim3(64), sizeof(u64) * (size_t)(cap + 1), s, h);
+  } else {
+    void (*kernel)(HgiParams) = prof ? pghi_hgi_offline_coop_kernel<true> : pghi_hgi_offline_coop_kernel<false>;
+    if (heap_lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds) != hipSuccess)
+      return AT_ELAUNCH;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(64), heap_lds, s, h);
+  }
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
