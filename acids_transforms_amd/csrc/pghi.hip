@@ -311,7 +311,13 @@ struct Heap {
   __device__ __forceinline__ u64 load_if(int pos, bool want, u64 dflt) const {
     const bool in_lds = pos < cap;
     u64 v = top[(want && in_lds) ? pos : 0];
-    if (want && !in_lds) v = gload(rest + pos);
+    if (want && !in_lds) {
+      v = gload(rest + pos);
+      // Wait for it here, inside the branch.  Left to the compiler, the wait lands after the join as vmcnt(0),
+      // and rounds that touched LDS only would then sit out the neighbourhood loads the pop has in flight
+      // (memory returns in order): an HBM round trip exposed on every pop.
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+    }
     return want ? v : dflt;
   }
 };
@@ -464,15 +470,16 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
       const int d = (lane == 0) ? F : (lane == 1) ? -F : (lane == 2) ? 1 : -1;
       const bool inb = (lane == 0) ? (col < T - 1) : (lane == 1) ? (col > 0) : (lane == 2) ? (row < F - 1)
                                                                                             : (lane == 3) && (row > 0);
-      float s = 0.f, g_c = 0.f, g_n = 0.f, pc = 0.f;
-      if (lane < 4 && inb) {
-        const int nb = c + d;
-        const float* gr = (lane < 2) ? fg : tg;
-        s = fload(spec + nb);
-        g_c = gr[c];
-        g_n = gr[nb];
-        pc = fload(phase + c);
-      }
+      // Every lane loads (out-of-range neighbours and lanes >= 4 re-read bin c itself: the same cache lines), and
+      // every loaded value is consumed outside any branch below.  A load the compiler has to treat as "maybe
+      // still pending" at the loop's back edge makes it drain vmcnt at the top of the next pop -- which then
+      // starts by sitting out the load of `last`, a deep heap entry, before it has issued anything else.
+      const int nb = inb ? c + d : c;
+      const float* gr = (lane < 2) ? fg : tg;
+      const float s = fload(spec + nb);
+      const float g_c = gr[c];
+      const float g_n = gr[nb];
+      const float pc = fload(phase + c);
       const long long t1 = PROF ? TICK() : 0;
       // heappop, part 2: bubble the smaller children up, drop `last` into the leaf, let it rise
       long long t2 = t1;
@@ -490,16 +497,16 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
         }
       }
       const long long t3 = PROF ? TICK() : 0;
-      const bool lv = (lane < 4) && inb && live(s, abstol, thr);
+      const float half = (g_c + g_n) / 2.0f;
+      const float new_phase = (lane & 1) ? pc - half : pc + half;
+      const bool lv = inb && live(s, abstol, thr);     // inb is false on lanes >= 4
       if (lv) {
-        const int nb = c + d;
-        const float half = (g_c + g_n) / 2.0f;
-        phase[nb] = (lane & 1) ? pc - half : pc + half;
+        phase[nb] = new_phase;
         spec[nb] = abstol;
       }
       const u64 lvmask = __ballot(lv);
       const long long t4 = PROF ? TICK() : 0;
-      const u64 mine = pack_item(-s, c + d);
+      const u64 mine = pack_item(-s, nb);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if ((lvmask >> q) & 1ull) {
