@@ -387,11 +387,12 @@ __device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64 a
     // "am I the child my parent bubbles up?"  children 2i (left, even lane) and 2i+1 (right, odd lane) are
     // DPP neighbours.  heapq.py:33: take the right child iff it exists and not (left < right); a missing child
     // reads as +inf (real keys are -magnitude, finite), so one compare `left < right` decides for both lanes.
+    // As lane masks (scalar unit): left children are chosen where key < sibling, right ones where not
+    // (sibling < key).
     const float sib = dpp_xor1(key);
-    const bool is_right = lane & 1;
-    const bool left_lt_right = is_right ? (sib < key) : (key < sib);
-    const bool chosen = valid && (left_lt_right != is_right);
-    const u64 W = __ballot(chosen && lane >= 2);
+    const u64 kOdd = 0xAAAAAAAAAAAAAAAAull;
+    const u64 m_lt = __ballot(key < sib), m_gt = __ballot(sib < key);
+    const u64 W = __ballot(valid) & ((~kOdd & m_lt) | (kOdd & ~m_gt)) & ~3ull;
     // The chain of bubbled-up nodes below the subtree root: node L belongs to it iff L and every ancestor of
     // L down to level 1 is its parent's chosen child, i.e. iff W covers the lane's ancestor mask; below a
     // leaf no bit is set, so the chain simply ends there.
