@@ -10,6 +10,7 @@
 // pass exactly as the fused STFT epilogue does (band_bank.h, utils/banded.py: conflict-free ds_read_b128 of
 // values and weights), and the epilogue writes N outputs.  HBM-bound: the input row in, N floats out.
 #include <hip/hip_runtime.h>
+#include "fastmath.h"
 #include <stdint.h>
 #include <type_traits>
 
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
         if (p.phase_out) {
           const int kk = lane + 64 * m;
           if (m + 1 < NSEG || kk < p.K) {
-            float ph = atan2f(cur[m].y, cur[m].x);
+            float ph = fast_atan2f(cur[m].y, cur[m].x);
             if (p.ph_offset) ph = (ph - ph_off) / ph_sc;
             p.phase_out[r * p.ld_phase + kk] = ph;
           }

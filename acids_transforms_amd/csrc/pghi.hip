@@ -15,6 +15,7 @@
 // This file is compiled with -ffp-contract=off: every fp32 expression keeps
 // the reference's rounding sequence (no FMA contraction).
 #include <hip/hip_runtime.h>
+#include "fastmath.h"
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(256) void rt_update_kernel(RtUpdParams p) {
     }
     p.hist_out[((long long)s * 2) * p.F + k] = prev;
     p.hist_out[((long long)s * 2 + 1) * p.F + k] = hypotf(re, im);
-    p.phase_out[i] = atan2f(im, re);
+    p.phase_out[i] = fast_atan2f(im, re);
   }
 }
 

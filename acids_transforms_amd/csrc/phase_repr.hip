@@ -12,6 +12,7 @@
 // every step of a wavefront reads/writes 64 consecutive elements of one frame row.  Loads do not depend on
 // the recurrence and are unrolled ahead of it.  HBM-bound: 8 (complex) or 4 (phase) bytes in, 4 out per bin.
 #include <hip/hip_runtime.h>
+#include "fastmath.h"
 #include <stdint.h>
 #include <type_traits>
 
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void phase_scan_kernel(ScanParams p) {
   using In = typename std::conditional<CPLX, float2, float>::type;
   const In* src = (CPLX ? reinterpret_cast<const In*>(p.X) : reinterpret_cast<const In*>(p.phase)) + base;
   auto to_phase = [](In v) -> float {
-    if constexpr (CPLX) return atan2f(v.y, v.x);
+    if constexpr (CPLX) return fast_atan2f(v.y, v.x);
     else return v;
   };
   double acc = 0.0;                 // torch.cumsum's accumulator on CPU
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void phase_angle_kernel(ScanParams p) {
     float v;
     if (CPLX) {
       const float2 z = p.X[i];
-      v = atan2f(z.y, z.x);
+      v = fast_atan2f(z.y, z.x);
     } else {
       v = p.phase[i];
     }

@@ -1,6 +1,7 @@
 // pointwise.hip -- small elementwise kernels around the spectral path.
 //   angle            x_fft.angle()                 reference stft.py:103, dgt.py:69, dgt.py:336   (K2)
 #include <hip/hip_runtime.h>
+#include "fastmath.h"
 #include <stdint.h>
 
 #include "../../include/acids_hip.h"
@@ -10,7 +11,7 @@ namespace at_hip {
 __global__ void angle_kernel(const float2* __restrict__ x, long long n, float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float2 v = x[i];
-    out[i] = atan2f(v.y, v.x);
+    out[i] = fast_atan2f(v.y, v.x);
   }
 }
 

@@ -13,6 +13,7 @@
 // registers across a run of frames.  No workgroup barrier anywhere; a
 // 256-thread block is just four independent waves sharing an LDS allocation.
 #include <hip/hip_runtime.h>
+#include "fastmath.h"
 #include <type_traits>
 #include <stdint.h>
 
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stft1024_fwd_kernel(FwdP
     if (WRITE_PHASE) {
       float* prow = p.phase + f * F;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) prow[lane + 64 * m] = atan2f(v[m].y, v[m].x);
-      if (lane == 0) prow[512] = atan2f(nyq.y, nyq.x);
+      for (int m = 0; m < 8; ++m) prow[lane + 64 * m] = fast_atan2f(v[m].y, v[m].x);
+      if (lane == 0) prow[512] = fast_atan2f(nyq.y, nyq.x);
     }
   }
 }
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
   auto flush_nyquist = [&]() {
     if (nyq_dst != nullptr && lane == 0) *nyq_dst = nyq_pending;
     if (WRITE_PHASE && nyq_dst != nullptr && lane == 0)
-      p.phase[(nyq_dst - p.out)] = atan2f(nyq_pending.y, nyq_pending.x);
+      p.phase[(nyq_dst - p.out)] = fast_atan2f(nyq_pending.y, nyq_pending.x);
   };
   auto frame_body = [&](float2 n6, float2 n7) {
     float2 v[8];
@@ -325,18 +326,18 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
     }
     if (WRITE_PHASE) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) prow[lane + 64 * m] = atan2f(v[m].y, v[m].x);
+      for (int m = 0; m < 8; ++m) prow[lane + 64 * m] = fast_atan2f(v[m].y, v[m].x);
       prow += F;
     }
     if (POLAR) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        float ph = atan2f(v[m].y, v[m].x);
+        float ph = fast_atan2f(v[m].y, v[m].x);
         if (p.ph_offset) ph = (ph - ph_off) / ph_sc;
         prow[lane + 64 * m] = ph;
       }
       if (lane == 0) {
-        float ph = atan2f(nyq.y, nyq.x);
+        float ph = fast_atan2f(nyq.y, nyq.x);
         if (p.ph_offset) ph = (ph - ph_off) / ph_sc;
         prow[512] = ph;
       }

@@ -4,6 +4,7 @@
 // Correctness path for the non-default sizes the parity tests use; the
 // n_fft = 1024 kernels in stft1024.hip are the tuned ones.
 #include <hip/hip_runtime.h>
+#include "fastmath.h"
 #include <stdint.h>
 
 namespace at_hip {
@@ -87,7 +88,7 @@ __global__ void rfft_generic_kernel(GenFwdParams p) {
     float2 X = make_float2(e.x + wd.y, e.y - wd.x);
     if (k == M) X = make_float2(Z[0].x - Z[0].y, 0.f);
     row[k] = X;
-    if (prow) prow[k] = atan2f(X.y, X.x);
+    if (prow) prow[k] = fast_atan2f(X.y, X.x);
   }
 }
 
