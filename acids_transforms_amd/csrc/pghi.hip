@@ -343,8 +343,8 @@ __device__ __forceinline__ void coop_siftdown(const Heap& H, int pos, u64 item, 
   const bool rises = (lane < depth) && (item_key(item) < item_key(anc));
   const u64 mask = __ballot(rises);
   const int m = (mask == ~0ull) ? 64 : __builtin_ctzll(~mask);  // item passes ancestors 0 .. m-1
-  if (lane < m) H.store(my_dst, anc);
-  else if (lane == m) H.store(my_dst, item);
+  // lanes 0 .. m-1 move their ancestor one step down, lane m drops the item: one store site
+  if (lane <= m) H.store(my_dst, lane == m ? item : anc);
 }
 
 // sibling's value through DPP (lane ^ 1): pure VALU, no LDS crossbar
