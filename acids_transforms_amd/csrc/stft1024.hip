@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
     for (int q = 0; q < p.bank.n_passes; ++q) table_floats += 64 * p.bank.pass_len[q];
     for (int i = threadIdx.x; i < table_floats; i += 64 * FWD_WAVES) wlds[i] = p.bank.weights[i];
     // per-lane walk descriptors behind the weights: re-read each frame (two ds_read_b32 per pass) rather
-    // than held in eight VGPRs -- the frame loop is at the 168-register limit of three waves per SIMD
+    // than held in two VGPRs per pass (up to 32 with a 16-pass bank)
     lane_tab = reinterpret_cast<int*>(wlds + table_floats);
     for (int i = threadIdx.x; i < 64 * p.bank.n_passes; i += 64 * FWD_WAVES) {
       lane_tab[i] = p.bank.lane_start[i];
