@@ -295,14 +295,21 @@ __device__ __forceinline__ void gstore(u64* p, u64 v) {
 // the rest in the clip's global workspace.  Same array, same indices -- only the storage differs.
 // cap = 2^k - 1 is chosen at launch from the batch size: 4095 entries (32 KB) while <= 4 clips share a
 // CU, fewer when more clips have to be resident at once.
-struct Heap {
+// SPILLS = false: the whole heap is in LDS (realtime kernel) and the global paths compile away.
+template <bool SPILLS>
+struct HeapT {
   u64* top;   // LDS, cap entries
   u64* rest;  // global, indexed by absolute position
   int cap;
   __device__ __forceinline__ u64 load(long long pos) const {
+    if constexpr (!SPILLS) return top[pos];
     return pos < cap ? top[pos] : gload(rest + pos);
   }
   __device__ __forceinline__ void store(long long pos, u64 v) const {
+    if constexpr (!SPILLS) {
+      top[pos] = v;
+      return;
+    }
     if (pos < cap) top[pos] = v;
     else gstore(rest + pos, v);
   }
@@ -310,6 +317,10 @@ struct Heap {
   // lanes that do not want it or whose entry is global): one divergent region -- the global load -- instead of
   // a nest of three, and none at all while the whole subtree is in LDS.
   __device__ __forceinline__ u64 load_if(int pos, bool want, u64 dflt) const {
+    if constexpr (!SPILLS) {
+      const u64 v = top[want ? pos : 0];
+      return want ? v : dflt;
+    }
     const bool in_lds = pos < cap;
     u64 v = top[(want && in_lds) ? pos : 0];
     if (want && !in_lds) {
@@ -322,6 +333,7 @@ struct Heap {
     return want ? v : dflt;
   }
 };
+typedef HeapT<true> Heap;
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
   const unsigned lo = __shfl((unsigned)v, src, 64);
   const unsigned hi = __shfl((unsigned)(v >> 32), src, 64);
@@ -333,7 +345,8 @@ __device__ __forceinline__ float fload(const float* p) {   // L2-served load of 
 }
 
 // place `item` at `pos` and let it rise (utils/heapq.py:9-21 with startpos = 0)
-__device__ __forceinline__ void coop_siftdown(const Heap& H, int pos, u64 item, int lane) {
+template <typename HEAP>
+__device__ __forceinline__ void coop_siftdown(const HEAP& H, int pos, u64 item, int lane) {
   const unsigned q = (unsigned)pos + 1u;
   const int depth = 31 - __clz(q);                // number of ancestors (< 31)
   const int sh = lane < 31 ? lane : 30;           // lanes >= depth are idle; keep their shifts defined
@@ -368,7 +381,8 @@ __device__ __forceinline__ u64 chain_mask(int lane) {
   return m;
 }
 
-__device__ __forceinline__ int coop_bubble(const Heap& H, int n, int lane, u64 anc_mask, u64& leaf_old) {
+template <typename HEAP>
+__device__ __forceinline__ int coop_bubble(const HEAP& H, int n, int lane, u64 anc_mask, u64& leaf_old) {
   int pos = 0;  // the hole
   const int lvl = 31 - __clz((unsigned)lane | 1u);
   const int off = lane - (1 << lvl);
@@ -843,7 +857,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
   float* tg0 = ph1 + F;        // padded tgradw rows f-1 and f
   float* tg1 = tg0 + F;
   float* fg1 = tg1 + F;        // padded fgradw row f
-  const Heap H = {reinterpret_cast<u64*>(fg1 + F + (F & 1)), nullptr, 0x7fffffff};
+  const HeapT<false> H = {reinterpret_cast<u64*>(fg1 + F + (F & 1)), nullptr, 0x7fffffff};
   const u64 anc_mask = chain_mask(lane);
   auto lds_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -895,9 +909,17 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
         ++hn;
         lds_sync();
       };
-      for (int k = 0; k < F; ++k) {  // :428-430
-        const float hv = ufloat(hrow[k]);
-        if (hv > abstol) push(-hv, k);
+      // :428-430 every live bin of row f-1, in bin order.  64 bins per LDS read, then a scalar walk over the live
+      // ones (one LDS round trip per bin costs as much as a fifth of the push it decides about)
+      for (int k0 = 0; k0 < F; k0 += 64) {
+        const float mine = (k0 + lane < F) ? hrow[k0 + lane] : 0.0f;
+        u64 live_bins = __ballot(mine > abstol);
+        while (live_bins) {
+          const int j = __builtin_ctzll(live_bins);
+          live_bins &= live_bins - 1;
+          const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j));
+          push(-hv, k0 + j);
+        }
       }
       while (max_val > abstol) {  // :433
         while (hn > 0) {
