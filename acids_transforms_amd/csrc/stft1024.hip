@@ -641,6 +641,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
     acc[6] = make_float2(0.f, 0.f);
     acc[7] = make_float2(0.f, 0.f);
   };
+  // reciprocal of the full-overlap envelope, shared by the steady-state loop and the edge steps: a hop's value
+  // must not depend on which of the two emitted it, i.e. on how the launch cut the clip into runs
+  const float2* env15 = reinterpret_cast<const float2*>(p.env + 15 * 256);
+  const float2 e15a = env15[lane], e15b = env15[lane + 64];
+  const float2 r0 = make_float2(1.0f / e15a.x, 1.0f / e15a.y), r1 = make_float2(1.0f / e15b.x, 1.0f / e15b.y);
   // edges of the run / of the clip: any frame or slot may be missing
   auto generic_step = [&]() {
     if (t <= t_have) {
@@ -657,8 +662,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
         const long long tt = j - 1 + q;
         if (tt >= 0 && tt < p.T) mask |= 1 << q;
       }
-      const float2* env = reinterpret_cast<const float2*>(p.env + mask * 256);
-      emit(j, env[lane], env[lane + 64]);
+      if (mask == 15) {
+        emit_fast(j, r0, r1);
+      } else {
+        const float2* env = reinterpret_cast<const float2*>(p.env + mask * 256);
+        emit(j, env[lane], env[lane + 64]);
+      }
     }
     advance();
     ++t;
@@ -669,9 +678,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
   long long fast_end = (j1 + 1 < t_have - 2) ? j1 + 1 : t_have - 2;   // inclusive
   while (t < fast_begin && t <= t_last) generic_step();
   if (t <= fast_end) {
-    const float2* env15 = reinterpret_cast<const float2*>(p.env + 15 * 256);
-    const float2 e0 = env15[lane], e1 = env15[lane + 64];
-    const float2 r0 = make_float2(1.0f / e0.x, 1.0f / e0.y), r1 = make_float2(1.0f / e1.x, 1.0f / e1.y);
     if (DEPTH == 2) {
       // two frames in flight, two frames per trip with q0 / q1 swapping roles
       auto fast_step = [&](RawFrame<IN_MODE>& q) {

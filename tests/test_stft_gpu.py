@@ -179,3 +179,29 @@ def test_griffin_lim(dev):
     assert sc < 0.35, sc
     d = A.DGT(inversion_mode="griffin_lim").to(dev)
     assert d.invert(d(x.to(dev)).abs()).shape == (2, 5888)
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_the_batch(dev):
+    """A clip's spectrum, features, inverse and PGHI reconstruction are the same bits whether it runs alone or
+    inside a 700-clip batch: the launchers cut clips into runs by occupancy, and PGHI sizes the LDS share of each
+    heap by the batch, so neither may leak into the arithmetic."""
+    torch.manual_seed(11)
+    x0 = torch.randn(1, 40000, device=dev) * 0.1
+    xb = torch.cat([x0, torch.randn(699, 40000, device=dev) * 0.1])
+    for make in (A.STFT, A.DGT):
+        t = make().to(dev)
+        X1, Xb = t(x0), t(xb)
+        assert torch.equal(X1[0], Xb[0])
+        assert torch.equal(t.invert(X1)[0], t.invert(Xb)[0])
+    mg = A.Magnitude(n_mels=128).to(dev)
+    st = A.STFT().to(dev)
+    comp = st + mg
+    comp.scale_data(xb[:4])
+    assert torch.equal(comp(x0)[0], comp(xb)[0])
+    d = A.DGT().to(dev)
+    m1 = d(x0).abs()
+    mb = d(torch.cat([x0, torch.randn(4199, 40000, device=dev) * 0.1])).abs()
+    alone = d.invert(m1, inversion_mode="pghi")[0]          # 16383-entry LDS heap top (checked against the oracle
+    for B in (300, 700, 1100, 2100, 4200):                   # elsewhere); 8191, 4095, 2047, 1023 and 511 entries
+        assert torch.equal(alone, d.invert(mb[:B], inversion_mode="pghi")[0]), B
