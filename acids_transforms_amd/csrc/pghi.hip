@@ -381,8 +381,10 @@ __device__ __forceinline__ u64 chain_mask(int lane) {
   return m;
 }
 
+// `top63`: positions 0..62 as lane L - 1 holds them (lane 0: anything), read by the caller before the pop began --
+// the first round always gathers from there, so its load is off the critical path.
 template <typename HEAP>
-__device__ __forceinline__ int coop_bubble(const HEAP& H, int n, int lane, u64 anc_mask, u64& leaf_old) {
+__device__ __forceinline__ int coop_bubble(const HEAP& H, int n, int lane, u64 anc_mask, u64& leaf_old, u64 top63) {
   int pos = 0;  // the hole
   const int lvl = 31 - __clz((unsigned)lane | 1u);
   const int off = lane - (1 << lvl);
@@ -393,11 +395,13 @@ __device__ __forceinline__ int coop_bubble(const HEAP& H, int n, int lane, u64 a
   // pay two as soon as D = 16 -- a third of all pops on dense spectra.  Same number of rounds either way.
   const int last_level = 31 - __clz((unsigned)n | 1u);
   int limit = last_level >= 1 ? ((last_level - 1) % 5) + 1 : 5;
+  bool first = true;
   for (;;) {
     // subtree under the hole: local node `lane` (1..63) <-> global index g
     const int g = ((pos + 1) << lvl) - 1 + off;           // < 2^25: heap positions are < T F < 2^31 >> 5
     const bool valid = (lane >= 1) && (lvl <= limit) && (g < n);
-    const u64 val = H.load_if(g, valid, kInf);
+    const u64 val = first ? (valid ? top63 : kInf) : H.load_if(g, valid, kInf);
+    first = false;
     const float key = item_key(val);
     // "am I the child my parent bubbles up?"  children 2i (left, even lane) and 2i+1 (right, odd lane) are
     // DPP neighbours.  heapq.py:33: take the right child iff it exists and not (left < right); a missing child
@@ -468,11 +472,12 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
       const long long t0 = PROF ? TICK() : 0;
       if (PROF) { s_depth += 31 - __clz((unsigned)hn | 1u); if (hn > hn_max) hn_max = hn; }
       // heappop, part 1: take the last entry off, read the root (heapq.py:51-56)
+      const u64 top63 = H.top[lane >= 1 ? lane - 1 : 0];   // root + the first bubble round's subtree, one read
       const u64 last = H.load(hn - 1);     // usually deep in the global part: not needed before the leaf is known
       hn -= 1;
       int c;
       if (hn == 0) c = uni(item_idx(last));
-      else c = uni(item_idx(H.top[0]));    // the root always lives in LDS: no wait on the (global) load above
+      else c = __builtin_amdgcn_readlane(item_idx(top63), 1);   // the root always lives in LDS: no wait on `last`
       if (order && !PROF && lane == 0) order[npops] = c;
       ++npops;
       // frame / bin of c without an integer division (~25 dependent instructions on the pop's critical path):
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_offline_coop_kernel(HgiParams p) 
       long long t2 = t1;
       if (hn > 0) {
         u64 leaf_old = 0;
-        const int leaf = coop_bubble(H, hn, lane, anc_mask, leaf_old);
+        const int leaf = coop_bubble(H, hn, lane, anc_mask, leaf_old, top63);
         t2 = PROF ? TICK() : 0;
         // `last` goes into the leaf and rises while it is smaller than its parent (heapq.py:39-42).  The
         // parent of the leaf now holds the entry that just left the leaf, which is still in registers: in
@@ -924,9 +929,10 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
       while (max_val > abstol) {  // :433
         while (hn > 0) {
           // heappop (heapq.py:51-59)
+          const u64 top63 = H.top[(lane >= 1 && lane - 1 < 4 * F + 8) ? lane - 1 : 0];   // the heap holds 4F + 8 entries
           const u64 last = H.load(hn - 1);
           hn -= 1;
-          const int idx = uni(item_idx(hn == 0 ? last : H.load(0)));
+          const int idx = uni(item_idx(hn == 0 ? last : readlane64(top63, 1)));
           const bool cur_row = idx >= F;
           const int k = cur_row ? idx - F : idx;
           // the magnitudes this pop may propagate to, requested before the heap repair (they come back first:
@@ -936,7 +942,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
           const float s_dn = srow[k >= 1 ? k - 1 : 0];
           if (hn > 0) {
             u64 leaf_old = 0;
-            const int leaf = coop_bubble(H, hn, lane, anc_mask, leaf_old);
+            const int leaf = coop_bubble(H, hn, lane, anc_mask, leaf_old, top63);
             if (leaf == 0 || !(item_key(last) < item_key(leaf_old))) {
               if (lane == 0) H.store(leaf, last);
             } else {
