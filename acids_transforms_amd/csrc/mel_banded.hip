@@ -311,9 +311,10 @@ template <int KQ>   // KQ = ceil(K / 4) quads of the row, <= 32
 __global__ __launch_bounds__(256) void small_proj_kernel(SmallProjParams p) {
   __shared__ float4 rowbuf[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float w[4 * KQ];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f w[2 * KQ];       // this lane's column of W, two rows per register pair (packed multiply-adds below)
 #pragma unroll
-  for (int k = 0; k < 4 * KQ; ++k) w[k] = (k < p.K && lane < p.N) ? p.W[(long long)k * p.N + lane] : 0.0f;
+  for (int k = 0; k < 4 * KQ; ++k) w[k >> 1][k & 1] = (k < p.K && lane < p.N) ? p.W[(long long)k * p.N + lane] : 0.0f;
   float off = 0.f, sc = 1.f;
   if (p.offset) {
     off = *p.offset;
@@ -331,37 +332,37 @@ __global__ __launch_bounds__(256) void small_proj_kernel(SmallProjParams p) {
   long long cb = (p.T > 0) ? r / p.T : 0, ct = (p.T > 0) ? r - cb * p.T : 0;
   long long run_t0 = ct;                          // first frame of this wave's rows inside the current clip
   const int k0 = 2 * lane;              // a row is K <= 128 floats: two per lane
+  // Rows r .. r+3 in flight in a ring of four register pairs with compile-time roles (copying a register whose load is
+  // still out waits for it, and a conditional load makes the compiler drain vmcnt on the spot: either way the
+  // "prefetch" degenerates to one row).  Loads are unconditional: rows past the end re-read the last row, floats past
+  // K re-read element K-1 and meet a zero weight.
+  const int ka = k0 < p.K ? k0 : p.K - 1, kb = k0 + 1 < p.K ? k0 + 1 : p.K - 1;
+  const long long last_row = r_end - 1;
   auto fetch = [&](long long row, float& a, float& b) {
-    const float* src = p.x + row * p.K;
-    a = (k0 < p.K) ? src[k0] : 0.0f;
-    b = (k0 + 1 < p.K) ? src[k0 + 1] : 0.0f;
+    const float* src = p.x + (row < last_row ? row : last_row) * p.K;
+    a = src[ka];
+    b = src[kb];
   };
-  float c0 = 0.f, c1 = 0.f, n0[3] = {0.f, 0.f, 0.f}, n1[3] = {0.f, 0.f, 0.f};
-  if (r < r_end) fetch(r, c0, c1);
+  float ra[4], rb[4];
+  if (r >= r_end) return;
 #pragma unroll
-  for (int d = 0; d < 3; ++d)
-    if (r + 1 + d < r_end) fetch(r + 1 + d, n0[d], n1[d]);
-  for (; r < r_end; ++r) {
-    // stage the current row; rows r+1 .. r+3 are already on their way, request r+4
-    buf[k0] = c0;
-    buf[k0 + 1] = c1;
-    c0 = n0[0]; c1 = n1[0];
-    n0[0] = n0[1]; n1[0] = n1[1];
-    n0[1] = n0[2]; n1[1] = n1[2];
-    if (r + 4 < r_end) fetch(r + 4, n0[2], n1[2]);
+  for (int d = 0; d < 4; ++d) fetch(r + d, ra[d], rb[d]);
+  auto row_step = [&](float& slot_a, float& slot_b) {
+    // stage the current row, then refill its slot with row r+4
+    buf[k0] = slot_a;
+    buf[k0 + 1] = slot_b;
+    fetch(r + 4, slot_a, slot_b);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four independent chains: one chain of K dependent fmas is latency-bound
+    v2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};          // four independent chains (k mod 4), two per packed fma
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const float4 v = rowbuf[wave][q];            // same address on every lane: LDS broadcast
-      a0 = fmaf(v.x, w[4 * q], a0);
-      a1 = fmaf(v.y, w[4 * q + 1], a1);
-      a2 = fmaf(v.z, w[4 * q + 2], a2);
-      a3 = fmaf(v.w, w[4 * q + 3], a3);
+      a01 = __builtin_elementwise_fma((v2f){v.x, v.y}, w[2 * q], a01);
+      a23 = __builtin_elementwise_fma((v2f){v.z, v.w}, w[2 * q + 1], a23);
     }
-    float acc = (a0 + a1) + (a2 + a3);
+    float acc = (a01.x + a01.y) + (a23.x + a23.y);
     if (p.offset) acc = (acc - off) / sc;
     if (p.T > 0) {
       const long long b = cb, t = ct;               // (clip, frame) of row r, tracked incrementally
@@ -387,6 +388,16 @@ __global__ __launch_bounds__(256) void small_proj_kernel(SmallProjParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ++r;
+  };
+  while (r < r_end) {
+    row_step(ra[0], rb[0]);
+    if (r >= r_end) break;
+    row_step(ra[1], rb[1]);
+    if (r >= r_end) break;
+    row_step(ra[2], rb[2]);
+    if (r >= r_end) break;
+    row_step(ra[3], rb[3]);
   }
 }
 
