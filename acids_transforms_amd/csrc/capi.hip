@@ -15,8 +15,8 @@ int launch_stft1024_fwd(const float*, long long, long long, long long, long long
 int launch_stft1024_h256_fwd(const float*, long long, long long, long long, long long, const float*, const float2*,
                              float2*, float*, const BandBank*, float*, const float*, const float*, float, int, int, int,
                              hipStream_t, const PolarOut* polar = nullptr);
-int launch_istft1024_ola(const float2*, const float*, const float*, long long, long long, const float*, const float*,
-                         const float2*, float*, hipStream_t);
+int launch_istft1024_ola(const float2*, const float*, const float*, long long, long long, int, const float*,
+                         const float*, const float2*, float*, hipStream_t);
 int launch_irfft1024_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
                             float*, hipStream_t);
 // stft_generic.hip
@@ -37,18 +37,19 @@ static const float2* twiddles_for_current_device() {
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-__global__ void envelope_table_kernel(const float* w, int n_fft, int hop, float* env16) {
-  // env16[mask][r] = sum over q in mask (ascending) of w[hop*(3-q) + r]^2; frames j-1+q, q = 0..3
+__global__ void envelope_table_kernel(const float* w, int n_fft, int hop, int R, float* env) {
+  // env[mask][r] = sum over q in mask (ascending) of w[hop*(R-1-q) + r]^2: the R = n_fft / hop frames that overlap a
+  // hop, oldest first
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 16 * hop) return;
+  if (i >= (1 << R) * hop) return;
   int mask = i / hop, r = i - mask * hop;
   float s = 0.f;
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < R; ++q)
     if (mask & (1 << q)) {
-      int o = hop * (3 - q) + r;
+      int o = hop * (R - 1 - q) + r;
       if (o < n_fft) s += w[o] * w[o];
     }
-  env16[i] = s;
+  env[i] = s;
 }
 }  // namespace at_hip
 
@@ -177,19 +178,22 @@ int at_stft_polar_forward(const float* x, int64_t B, int64_t L, int64_t clip_str
 
 int at_istft_envelope_table(const float* inv_window, int n_fft, int hop, float* env16, void* stream) {
   if (!inv_window || !env16 || hop <= 0 || n_fft <= 0) return AT_EINVAL;
-  int total = 16 * hop;
+  if (n_fft % hop) return AT_EUNSUPPORTED;
+  const int R = n_fft / hop;
+  if (R != 2 && R != 4 && R != 8) return AT_EUNSUPPORTED;
+  int total = (1 << R) * hop;
   hipLaunchKernelGGL(envelope_table_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, inv_window,
-                     n_fft, hop, env16);
+                     n_fft, hop, R, env16);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
 static bool istft_fast(int n_fft, int hop, const float* env16, const float* w) {
-  return n_fft == 1024 && hop == 256 && env16 != nullptr && (((uintptr_t)w) & 7) == 0 &&
+  return n_fft == 1024 && (hop == 128 || hop == 256 || hop == 512) && env16 != nullptr && (((uintptr_t)w) & 7) == 0 &&
          (((uintptr_t)env16) & 7) == 0;
 }
 
 size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop) {
-  if (n_fft == 1024 && hop == 256) return 0;
+  if (n_fft == 1024 && (hop == 128 || hop == 256 || hop == 512)) return 0;   // with the envelope table; see at_istft
   return (size_t)B * (size_t)T * (size_t)n_fft * sizeof(float);
 }
 
@@ -205,7 +209,7 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
   if (istft_fast(n_fft, hop, env16, inv_window) && (((uintptr_t)y) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();
     if (!tw) return AT_ENOTINIT;
-    return launch_istft1024_ola((const float2*)X_complex, mag, phase, B, T, inv_window, env16, tw, y, s);
+    return launch_istft1024_ola((const float2*)X_complex, mag, phase, B, T, hop, inv_window, env16, tw, y, s);
   }
   size_t need = (size_t)B * (size_t)T * (size_t)n_fft * sizeof(float);
   if (!workspace || workspace_bytes < need) return AT_EWORKSPACE;

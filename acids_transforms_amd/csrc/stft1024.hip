@@ -563,14 +563,20 @@ __device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const 
   }
 }
 
-// K3: irFFT + window + overlap-add (hop = 256 = N/4) + envelope division + centre trim.
-// A wave produces output hop-slots [j0, j1) of one clip, streaming over frames j0-1 .. j1+1 with the four
+// K3: irFFT + window + overlap-add + envelope division + centre trim, for hop = 128 HS (HS = 1, 2, 4: N/8, N/4 --
+// the reference's default --, N/2).  A lane's eight registers are eight 128-sample slots of the padded signal, a hop
+// is HS of them, R = 8 / HS frames overlap and the centre trim is C = 4 / HS hops.
+// A wave produces output hop-slots [j0, j1) of one clip, streaming over frames j0+C-(R-1) .. j1-1+C with the R
 // overlapping frames' partial sums in registers.  Spectra are requested two frames ahead (8 KB per wave in
 // flight); the steady-state loop is branch-free so that the compiler's vmcnt accounting leaves those loads
 // and the previous outputs' stores in flight across iterations (a conditional load anywhere in the loop
 // collapses every wait to vmcnt(0)).
-template <int IN_MODE, int DEPTH, bool TWLDS>
+template <int IN_MODE, int DEPTH, bool TWLDS, int HS = 2>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void istft1024_ola_kernel(InvParams p) {
+  constexpr int R = 8 / HS;          // overlapping frames
+  constexpr int C = 4 / HS;          // centre trim in hops
+  constexpr int H = 128 * HS;        // hop in samples
+  constexpr int kFull = (1 << R) - 1;
   __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave + 512 + (TWLDS ? kTwiddleCount : 0)];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -605,16 +611,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
   for (int m = 0; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
 
   const long long fbase = b * p.T;
-  float* yclip = p.y + b * (256 * nslots);
-  long long t = (j0 > 0) ? j0 - 1 : 0;
-  const long long t_last = j1 + 1;                                  // inclusive; frames >= T contribute nothing
+  float* yclip = p.y + b * (H * nslots);
+  long long t = (j0 + C - (R - 1) > 0) ? j0 + C - (R - 1) : 0;
+  const long long t_last = j1 - 1 + C;                              // inclusive; frames >= T contribute nothing
   const long long t_have = (t_last < p.T - 1) ? t_last : p.T - 1;   // last frame this run reads
 
   RawFrame<IN_MODE> q0 = {}, q1 = {};   // frames t and t + 1
   if (t <= t_have) load_raw(p, fbase + t, lane, q0);
   if (t + 1 <= t_have) load_raw(p, fbase + t + 1, lane, q1);
 
-  // accumulators start aligned with frame t: acc[m] covers padded samples t*256 + 2*(lane+64m)
+  // accumulators start aligned with frame t: acc[m] covers padded samples t*H + 2*(lane+64m)
   auto consume = [&](const RawFrame<IN_MODE>& q) {
     float2 v[8];
     float nyq;
@@ -623,29 +629,38 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc[m] = cadd(acc[m], v[m]);
   };
-  auto emit = [&](long long j, float2 e0, float2 e1) {
-    float2* dst = reinterpret_cast<float2*>(yclip + j * 256);
-    dst[lane] = make_float2(acc[0].x / e0.x, acc[0].y / e0.y);
-    dst[lane + 64] = make_float2(acc[1].x / e1.x, acc[1].y / e1.y);
+  auto emit = [&](long long j, const float2* env) {
+    float2* dst = reinterpret_cast<float2*>(yclip + j * H);
+#pragma unroll
+    for (int k = 0; k < HS; ++k) {
+      const float2 e = env[lane + 64 * k];
+      dst[lane + 64 * k] = make_float2(acc[k].x / e.x, acc[k].y / e.y);
+    }
   };
   // steady state: the envelope of a fully overlapped hop is the same for every frame, so its reciprocal is taken
   // once per wave (an fp32 division is ~10 instructions, four of them per frame); at most one ulp from acc / e
-  auto emit_fast = [&](long long j, float2 r0, float2 r1) {
-    float2* dst = reinterpret_cast<float2*>(yclip + j * 256);
-    dst[lane] = make_float2(acc[0].x * r0.x, acc[0].y * r0.y);
-    dst[lane + 64] = make_float2(acc[1].x * r1.x, acc[1].y * r1.y);
-  };
-  auto advance = [&]() {   // one hop = two register slots
+  float2 rcp[HS];
+  auto emit_fast = [&](long long j) {
+    float2* dst = reinterpret_cast<float2*>(yclip + j * H);
 #pragma unroll
-    for (int m = 0; m < 6; ++m) acc[m] = acc[m + 2];
-    acc[6] = make_float2(0.f, 0.f);
-    acc[7] = make_float2(0.f, 0.f);
+    for (int k = 0; k < HS; ++k) dst[lane + 64 * k] = make_float2(acc[k].x * rcp[k].x, acc[k].y * rcp[k].y);
+  };
+  auto advance = [&]() {   // one hop = HS register slots
+#pragma unroll
+    for (int m = 0; m < 8 - HS; ++m) acc[m] = acc[m + HS];
+#pragma unroll
+    for (int m = 8 - HS; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
   };
   // reciprocal of the full-overlap envelope, shared by the steady-state loop and the edge steps: a hop's value
   // must not depend on which of the two emitted it, i.e. on how the launch cut the clip into runs
-  const float2* env15 = reinterpret_cast<const float2*>(p.env + 15 * 256);
-  const float2 e15a = env15[lane], e15b = env15[lane + 64];
-  const float2 r0 = make_float2(1.0f / e15a.x, 1.0f / e15a.y), r1 = make_float2(1.0f / e15b.x, 1.0f / e15b.y);
+  {
+    const float2* env_full = reinterpret_cast<const float2*>(p.env + kFull * H);
+#pragma unroll
+    for (int k = 0; k < HS; ++k) {
+      const float2 e = env_full[lane + 64 * k];
+      rcp[k] = make_float2(1.0f / e.x, 1.0f / e.y);
+    }
+  }
   // edges of the run / of the clip: any frame or slot may be missing
   auto generic_step = [&]() {
     if (t <= t_have) {
@@ -654,28 +669,24 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
       if (t + 2 <= t_have) load_raw(p, fbase + t + 2, lane, q1);
       consume(cur);
     }
-    const long long j = t - 2;  // padded slot t is complete -> output slot j, fed by frames j-1 .. j+2
+    const long long j = t - C;  // padded hop t is complete -> output slot j, fed by frames t-(R-1) .. t
     if (j >= j0 && j < j1) {
       int mask = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long long tt = j - 1 + q;
+      for (int q = 0; q < R; ++q) {
+        const long long tt = t - (R - 1) + q;
         if (tt >= 0 && tt < p.T) mask |= 1 << q;
       }
-      if (mask == 15) {
-        emit_fast(j, r0, r1);
-      } else {
-        const float2* env = reinterpret_cast<const float2*>(p.env + mask * 256);
-        emit(j, env[lane], env[lane + 64]);
-      }
+      if (mask == kFull) emit_fast(j);
+      else emit(j, reinterpret_cast<const float2*>(p.env + mask * H));
     }
     advance();
     ++t;
   };
 
-  // steady state: frames t .. t+2 exist, slot t-2 belongs to this run and has all four contributors
-  long long fast_begin = j0 + 2 > 3 ? j0 + 2 : 3;
-  long long fast_end = (j1 + 1 < t_have - 2) ? j1 + 1 : t_have - 2;   // inclusive
+  // steady state: frames t .. t+2 exist, slot t-C belongs to this run and has all R contributors
+  long long fast_begin = j0 + C > R - 1 ? j0 + C : R - 1;
+  long long fast_end = (j1 - 1 + C < t_have - 2) ? j1 - 1 + C : t_have - 2;   // inclusive
   while (t < fast_begin && t <= t_last) generic_step();
   if (t <= fast_end) {
     if (DEPTH == 2) {
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
         const RawFrame<IN_MODE> cur = q;
         load_raw(p, fbase + t + 2, lane, q);
         consume(cur);
-        emit_fast(t - 2, r0, r1);
+        emit_fast(t - C);
         advance();
         ++t;
       };
@@ -699,7 +710,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
         const RawFrame<IN_MODE> cur = q0;
         load_raw(p, fbase + t + 1, lane, q0);
         consume(cur);
-        emit_fast(t - 2, r0, r1);
+        emit_fast(t - C);
         advance();
       }
       q1 = {};
@@ -861,7 +872,7 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, long long B, long long T,
+int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, long long B, long long T, int hop,
                          const float* window, const float* env16, const float2* tw, float* y, hipStream_t stream) {
   InvParams p = {};
   p.X = X; p.mag = mag; p.phase = phase; p.window = window; p.env = env16; p.tw = tw; p.y = y;
@@ -870,10 +881,14 @@ int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, 
   if (B == 0 || nslots <= 0) return 0;
   // two frames in flight per wave, twiddles in registers: 2 waves per SIMD.  (One frame in flight at 3 waves,
   // or LDS twiddles at 3-4 waves, all land within 3 % of each other: the kernel sits on its memory floor.)
-  void (*kernel)(InvParams) = X ? istft1024_ola_kernel<IN_COMPLEX, 2, false> : istft1024_ola_kernel<IN_POLAR, 2, false>;
-  // runs of >= 32 hop slots: a run synthesises 3 frames more than it emits slots
+  void (*kernel)(InvParams) = nullptr;
+  if (hop == 128) kernel = X ? istft1024_ola_kernel<IN_COMPLEX, 2, false, 1> : istft1024_ola_kernel<IN_POLAR, 2, false, 1>;
+  else if (hop == 256) kernel = X ? istft1024_ola_kernel<IN_COMPLEX, 2, false, 2> : istft1024_ola_kernel<IN_POLAR, 2, false, 2>;
+  else if (hop == 512) kernel = X ? istft1024_ola_kernel<IN_COMPLEX, 2, false, 4> : istft1024_ola_kernel<IN_POLAR, 2, false, 4>;
+  else return -1;
+  // runs of >= 32 hop slots: a run synthesises n_fft/hop - 1 frames more than it emits slots
   const long long slots = resident_waves(kernel, 64 * WAVES_PER_BLOCK, 0);
-  const long long spr = plan_units_per_run(B, nslots, slots, 32, 3);
+  const long long spr = plan_units_per_run(B, nslots, slots, 32, 1024 / hop - 1);
   p.slots_per_run = spr;
   p.runs_per_clip = (nslots + spr - 1) / spr;
   const long long waves = B * p.runs_per_clip;

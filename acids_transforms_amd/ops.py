@@ -40,7 +40,7 @@ def stft_forward(x, window, n_fft, hop, center=True, want_phase=False, T=None, c
 
 def istft_envelope_table(inv_window, n_fft, hop):
     require_device(inv_window)
-    env = torch.empty((16, hop), dtype=torch.float32, device=inv_window.device)
+    env = torch.empty((1 << (n_fft // hop), hop), dtype=torch.float32, device=inv_window.device)
     check(lib().at_istft_envelope_table(ptr(inv_window), n_fft, hop, ptr(env), stream_ptr()), "at_istft_envelope_table")
     return env
 

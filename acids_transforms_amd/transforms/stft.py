@@ -117,17 +117,19 @@ class STFT(AudioTransform):
         return self._get_window()
 
     def _make_env16(self) -> torch.Tensor:
-        """Window-envelope table of the fused n_fft=4*hop overlap-add kernel:
-        env[mask][r] = sum_{q in mask} w[hop*(3-q)+r]^2 (frames in ascending order)."""
+        """Window-envelope table of the fused overlap-add kernel (n_fft = R * hop, R = 2, 4 or 8):
+        env[mask][r] = sum_{q in mask} w[hop*(R-1-q)+r]^2 over the R frames that overlap a hop, oldest first.
+        (The name dates from R = 4, the reference's default n_fft = 4 * hop: 16 masks.)"""
         n, h = self._n_fft, self._hop
-        if n != 4 * h:
+        if n % h or n // h not in (2, 4, 8):
             return torch.zeros(0)
+        R = n // h
         w2 = self.inv_window[:n].detach().cpu() ** 2
-        env = torch.zeros(16, h)
-        for mask in range(16):
-            for q in range(4):
+        env = torch.zeros(1 << R, h)
+        for mask in range(1 << R):
+            for q in range(R):
                 if mask & (1 << q):
-                    env[mask] = env[mask] + w2[h * (3 - q):h * (4 - q)]
+                    env[mask] = env[mask] + w2[h * (R - 1 - q):h * (R - q)]
         return env
 
     @property

@@ -86,8 +86,10 @@ int at_stft_polar_forward(const float *x, int64_t B, int64_t L, int64_t clip_str
                           const float *phase_offset, const float *phase_scale, float *out_stacked, void *stream);
 
 /* ---- K3/K5/K15: inverse ------------------------------------------------ */
-/* 16 x hop table of window^2 sums used by at_istft for n_fft=1024, hop=256
- * (torch.istft's window envelope; stft.py:126-127).  env16: 16*hop floats. */
+/* 2^R x hop table of window^2 sums (R = n_fft / hop = 2, 4 or 8: the frames that overlap one hop) used by the fused
+ * at_istft path, n_fft = 1024 with hop = 512, 256 (the reference's default) or 128 -- torch.istft's window envelope
+ * (stft.py:126-127) for every combination of present / missing neighbour frames.  env16: 2^R * hop floats.
+ * Other ratios: AT_EUNSUPPORTED (at_istft then takes its workspace path). */
 int at_istft_envelope_table(const float *inv_window, int n_fft, int hop, float *env16, void *stream);
 
 size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop);
@@ -96,7 +98,8 @@ size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop);
  *     replaces stft.py:120-128, dgt.py:86-93 (complex input: X != NULL), and
  *     `x * exp(1j*phase)` + istft, stft.py:157-161 / dgt.py:152-154
  *     (polar input: X == NULL, mag and phase given).
- * y: (B, hop*(T-1)).  env16 may be NULL unless n_fft=1024 && hop=256. */
+ * y: (B, hop*(T-1)).  env16 (at_istft_envelope_table) is required for n_fft=1024 with hop=128, 256 or 512 -- the
+ * fused kernel, for which at_istft_workspace_bytes is 0 -- and may be NULL otherwise. */
 int at_istft(const float *X_complex, const float *mag, const float *phase, int64_t B, int64_t T, int n_fft, int hop,
              const float *inv_window, const float *env16, float *y, void *workspace, size_t workspace_bytes,
              void *stream);
