@@ -14,7 +14,7 @@ int launch_stft1024_fwd(const float*, long long, long long, long long, long long
                         const float2*, float2*, float*, hipStream_t);
 int launch_stft1024_h256_fwd(const float*, long long, long long, long long, long long, const float*, const float2*,
                              float2*, float*, const BandBank*, float*, const float*, const float*, float, int, int, int,
-                             hipStream_t, const PolarOut* polar = nullptr);
+                             hipStream_t, const PolarOut* polar = nullptr, int hop = 256);
 int launch_istft1024_ola(const float2*, const float*, const float*, long long, long long, int, const float*,
                          const float*, const float2*, float*, hipStream_t);
 int launch_irfft1024_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
@@ -112,9 +112,9 @@ int at_stft_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, i
   if (n_fft == 1024 && (((uintptr_t)window) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();
     if (!tw) return AT_ENOTINIT;
-    if (hop == 256 && center && (clip_stride & 1) == 0)
+    if ((hop == 256 || hop == 128 || hop == 512) && center && (clip_stride & 1) == 0)
       return launch_stft1024_h256_fwd(x, B, L, clip_stride, T, window, tw, (float2*)out_complex, phase, nullptr,
-                                      nullptr, nullptr, nullptr, 0.f, 0, 0, 0, s);
+                                      nullptr, nullptr, nullptr, 0.f, 0, 0, 0, s, nullptr, hop);
     return launch_stft1024_fwd(x, B, L, clip_stride, T, hop, center, window, tw, (float2*)out_complex, phase, s);
   }
   return launch_rfft_generic(x, B, L, clip_stride, T, n_fft, hop, center, window, (float2*)out_complex, phase, s);

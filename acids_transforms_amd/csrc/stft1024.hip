@@ -197,8 +197,11 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
 // lane its own row of the (B, N, T) tensor), which leaves partly written lines to be evicted and re-fetched.
 // POLAR (with MEL == 2): besides the features, normalise(angle X) of every bin goes to p.phase with row stride
 // p.phase_ld -- Compose(STFT + Polar) in one kernel, the complex spectrum never reaches HBM.
-template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false>
+// HS: hop in 128-sample register slots (1, 2 = the reference's default hop 256, 4): the window slides HS slots per
+// frame and HS new segments are fetched.
+template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2>
 __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
+  constexpr int H = 128 * HS;
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
   __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
   extern __shared__ float4 band_lds[];   // MEL != 0: the bank's weight table, sized by the launcher
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
   // first frame of the run: all eight segments
   float2 raw[8];
   {
-    const long long s0 = t0 * 256 - 512;
+    const long long s0 = t0 * H - 512;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const long long i0 = s0 + 128 * m;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
     if (WRITE_PHASE && nyq_dst != nullptr && lane == 0)
       p.phase[(nyq_dst - p.out)] = fast_atan2f(nyq_pending.y, nyq_pending.x);
   };
-  auto frame_body = [&](float2 n6, float2 n7) {
+  auto frame_body = [&](const float2 (&fresh)[HS]) {
     float2 v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -302,9 +305,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
       v[m] = make_float2(raw[m].x * w.x, raw[m].y * w.y);
     }
 #pragma unroll
-    for (int m = 0; m < 6; ++m) raw[m] = raw[m + 2];
-    raw[6] = n6;
-    raw[7] = n7;
+    for (int m = 0; m < 8 - HS; ++m) raw[m] = raw[m + HS];
+#pragma unroll
+    for (int k = 0; k < HS; ++k) raw[8 - HS + k] = fresh[k];
     float2 nyq;
     {
       v2f z[8];
@@ -421,32 +424,38 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
     row += F;
   };
 
-  // Frames whose successor's new samples [256 t + 512, 256 t + 768) lie inside the clip take the
-  // branch-free loop: two unconditional 8-byte loads issued *before* this frame's stores, so the
+  // Frames whose successor's new samples [H t + 512, H (t + 1) + 512) lie inside the clip take the
+  // branch-free loop: HS unconditional 8-byte loads issued *before* this frame's stores, so the
   // compiler's vmcnt accounting lets the stores stay in flight across iterations.
   long long t = t0;
-  long long t_fast_end = (L >= 768) ? (L - 768) / 256 + 1 : 0;   // first t whose successor needs reflection
+  long long t_fast_end = (L >= 512) ? (L - 512) / H : 0;         // first t whose successor needs reflection
   if (t_fast_end > t1 - 1) t_fast_end = t1 - 1;        // the last frame of the run has no successor to fetch
   if (!clip_aligned) t_fast_end = t0;                  // odd-length clips: generic loop only
   if (t < t_fast_end) {
-    const float2* nsrc = reinterpret_cast<const float2*>(clip + (t + 1) * 256 + 256) + lane;  // segment 6 of frame t+1
+    // segment 8 - HS of frame t+1 starts at original sample H (t+1) - 512 + 128 (8 - HS) = H t + 512
+    const float2* nsrc = reinterpret_cast<const float2*>(clip + t * H + 512) + lane;
     for (; t < t_fast_end; ++t) {
       flush_nyquist();
-      const float2 n6 = nsrc[0];
-      const float2 n7 = nsrc[64];
-      nsrc += 128;
-      frame_body(n6, n7);
+      float2 fresh[HS];
+#pragma unroll
+      for (int k = 0; k < HS; ++k) fresh[k] = nsrc[64 * k];
+      nsrc += H / 2;
+      frame_body(fresh);
     }
   }
   for (; t < t1; ++t) {
     flush_nyquist();
-    float2 n6 = make_float2(0.f, 0.f), n7 = n6;
+    float2 fresh[HS];
+#pragma unroll
+    for (int k = 0; k < HS; ++k) fresh[k] = make_float2(0.f, 0.f);
     if (t + 1 < t1) {
-      const long long i6 = (t + 1) * 256 - 512 + 768;
-      n6 = load_pair(clip, L, i6, i6 >= 0 && i6 + 128 <= L, clip_aligned, lane2);
-      n7 = load_pair(clip, L, i6 + 128, i6 + 128 >= 0 && i6 + 256 <= L, clip_aligned, lane2);
+#pragma unroll
+      for (int k = 0; k < HS; ++k) {
+        const long long i0 = t * H + 512 + 128 * k;
+        fresh[k] = load_pair(clip, L, i0, i0 >= 0 && i0 + 128 <= L, clip_aligned, lane2);
+      }
     }
-    frame_body(n6, n7);
+    frame_body(fresh);
   }
   flush_nyquist();
 }
@@ -826,7 +835,8 @@ int launch_stft1024_fwd(const float* x, long long B, long long L, long long clip
 int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long clip_stride, long long T,
                              const float* window, const float2* tw, float2* out, float* phase, const BandBank* bank,
                              float* feat, const float* offset, const float* scale, float eps, int contrast, int power2,
-                             int feat_channel_major, hipStream_t stream, const PolarOut* polar) {
+                             int feat_channel_major, hipStream_t stream, const PolarOut* polar, int hop) {
+  if (hop != 256 && (bank || (hop != 128 && hop != 512))) return -1;   // the fused epilogues are built for hop 256
   FwdRunParams p = {};
   p.x = x; p.window = window; p.tw = tw; p.out = out; p.phase = phase;
   p.B = B; p.L = L; p.clip_stride = clip_stride; p.T = T;
@@ -852,7 +862,12 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   int NW = 4;
   void (*kernel)(FwdRunParams) = nullptr;
   if (!bank) {
-    kernel = phase ? stft1024_h256_fwd_kernel<true, 0, 4, false> : stft1024_h256_fwd_kernel<false, 0, 4, false>;
+    if (hop == 128)
+      kernel = phase ? stft1024_h256_fwd_kernel<true, 0, 4, false, 0, false, 1> : stft1024_h256_fwd_kernel<false, 0, 4, false, 0, false, 1>;
+    else if (hop == 512)
+      kernel = phase ? stft1024_h256_fwd_kernel<true, 0, 4, false, 0, false, 4> : stft1024_h256_fwd_kernel<false, 0, 4, false, 0, false, 4>;
+    else
+      kernel = phase ? stft1024_h256_fwd_kernel<true, 0, 4, false> : stft1024_h256_fwd_kernel<false, 0, 4, false>;
   } else {
     NW = 8;
     if (!out && !polar && feat_channel_major && bank->n_passes == 1) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 1>;
@@ -861,10 +876,10 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     else if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true>;
     else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true> : stft1024_h256_fwd_kernel<false, 1, 8, true>;
   }
-  // runs of at least 24 frames so that the 3 extra segment loads of a run start stay < 5 % (counted as one
-  // frame of overhead per run)
+  // runs of at least 24 frames so that the extra segment loads of a run start stay < 5 % (counted as
+  // 1024 / hop - 3 >= 1 frames of overhead per run)
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
-  const long long fpr = plan_units_per_run(B, T, slots, 24, 1);
+  const long long fpr = plan_units_per_run(B, T, slots, 24, hop == 128 ? 5 : 1);
   p.frames_per_run = fpr;
   p.runs_per_clip = (T + fpr - 1) / fpr;
   const long long waves = B * p.runs_per_clip;

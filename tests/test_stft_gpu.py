@@ -205,3 +205,40 @@ def test_results_do_not_depend_on_the_batch(dev):
     alone = d.invert(m1, inversion_mode="pghi")[0]          # 16383-entry LDS heap top (checked against the oracle
     for B in (300, 700, 1100, 2100, 4200):                   # elsewhere); 8191, 4095, 2047, 1023 and 511 entries
         assert torch.equal(alone, d.invert(mb[:B], inversion_mode="pghi")[0]), B
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop", [128, 256, 512])
+def test_other_hops_take_the_sliding_kernels(dev, hop):
+    """n_fft = 1024 with hop = n_fft/8, /4 (reference default), /2: the sliding-window forward and the fused
+    overlap-add inverse (8, 4 or 2 overlapping frames), STFT and DGT windows, clip lengths down to the shortest torch
+    accepts, against the oracle; plus the phase side output and batch independence."""
+    for cls in (A.STFT, A.DGT):
+        t = cls(n_fft=1024, hop_length=hop).to(dev)
+        w, wi = t.window[:1024].cpu(), t.inv_window[:1024].cpu()
+        for L in (40000, 4096, 5000, 2047, 1536, 1024, 513):
+            torch.manual_seed(hop + L)
+            x = torch.randn(3, L) * 0.1
+            X = t(x.to(dev))
+            Xr = O.stft_forward(x, w, 1024, hop)
+            assert X.shape == Xr.shape
+            assert rel_max(X.cpu().numpy(), Xr.numpy()) < TOL, (cls.__name__, L)
+            y, yr = t.invert(X).cpu(), O.istft(Xr, wi, 1024, hop)
+            assert y.shape == yr.shape
+            if yr.numel():
+                assert rel_max(y.numpy(), yr.numpy()) < TOL, (cls.__name__, L)
+    from acids_transforms_amd import ops
+    st = A.STFT(n_fft=1024, hop_length=hop).to(dev)
+    st.eager_phase = True                       # angle() inside the forward kernel, like the reference's forward
+    torch.manual_seed(3)
+    x0 = torch.randn(1, 30000, device=dev) * 0.1
+    xb = torch.cat([x0, torch.randn(299, 30000, device=dev) * 0.1])
+    X0, Xb = st(x0), st(xb)
+    ph = st.phase_buffer
+    assert torch.equal(X0[0], Xb[0]) and torch.equal(st.invert(X0)[0], st.invert(Xb)[0])
+    big = Xb.abs().reshape(ph.shape) > 1e-2
+    d = (ph - Xb.angle().reshape(ph.shape) + np.pi) % (2 * np.pi) - np.pi
+    assert float(d[big].abs().max()) < 1e-5
+    # polar input to the fused inverse
+    yp = ops.istft(None, st.inv_window[:1024], 1024, hop, env16=st._env16, mag=Xb.abs(), phase=Xb.angle())
+    assert rel_max(yp.cpu().numpy(), st.invert(Xb).cpu().numpy()) < TOL
