@@ -398,9 +398,34 @@ def main():
                 "note": "torch fill_/copy_/sum on 2 GiB fp32 buffers: the practical ceiling for the fractions above "
                         "(roofline.peak stays the 8 TB/s spec)"}
 
+    def extra_other_hops():
+        # n_fft = 1024 at the other hops the sliding kernels cover (hop 128: 1379 frames per clip, 5.8 GB of spectrum)
+        res = {}
+        for hop in (128, 512):
+            st = A.STFT(sr=SR, n_fft=N_FFT, hop_length=hop).to(dev)
+            Xh = st(x)
+            st.invert(Xh)
+            torch.cuda.synchronize()
+            e = [ev() for _ in range(3)]
+            e[0].record()
+            for _ in range(3):
+                Xh = st(x)
+            e[1].record()
+            for _ in range(3):
+                st.invert(Xh)
+            e[2].record()
+            torch.cuda.synchronize()
+            f_ms, i_ms = e[0].elapsed_time(e[1]) / 3, e[1].elapsed_time(e[2]) / 3
+            frames = B * Xh.shape[-2]
+            res["hop_%d" % hop] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(f_ms, 4), "inverse_ms": round(i_ms, 4),
+                                   "frames_per_s_fwd_plus_inv": frames / ((f_ms + i_ms) * 1e-3)}
+            del Xh
+        return res
+
     if not args.no_extras:
         if rank == 0:
             guarded("hbm_probe", extra_hbm_probe)
+            guarded("other_hops", extra_other_hops)
             guarded("phase_representations", extra_phase_repr)
             guarded("mfcc40_forward", extra_mfcc40)
         if world > 1 and not rehearsal:
