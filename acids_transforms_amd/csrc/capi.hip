@@ -127,7 +127,8 @@ int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_strid
                         float* out_complex_or_null, float* phase_or_null, float* feat, int feat_channel_major,
                         void* stream) {
   if (B < 0 || T < 0 || L < 0) return AT_EINVAL;
-  if (n_fft != 1024 || hop != 256 || (clip_stride & 1)) return AT_EUNSUPPORTED;
+  if (n_fft != 1024 || (hop != 256 && hop != 128 && hop != 512) || (clip_stride & 1)) return AT_EUNSUPPORTED;
+  if (hop != 256 && feat_channel_major) return AT_EUNSUPPORTED;
   if (B * T == 0) return AT_OK;
   if (!x || !window || !feat || !lane_filter || !lane_start || !band_weights || !pass_len_host) return AT_EINVAL;
   if (n_filters <= 0 || n_passes <= 0 || n_passes > 16 || n_filters > 64 * n_passes) return AT_EINVAL;
@@ -144,7 +145,8 @@ int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_strid
   }
   if (table_floats > 8192) return AT_EUNSUPPORTED;   // LDS copy of the band weights
   return launch_stft1024_h256_fwd(x, B, L, clip_stride, T, window, tw, (float2*)out_complex_or_null, phase_or_null, &bank,
-                                  feat, offset, scale, eps, contrast, power2, feat_channel_major, (hipStream_t)stream);
+                                  feat, offset, scale, eps, contrast, power2, feat_channel_major, (hipStream_t)stream,
+                                  nullptr, hop);
 }
 
 int at_stft_polar_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,

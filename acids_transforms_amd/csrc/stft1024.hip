@@ -836,7 +836,10 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
                              const float* window, const float2* tw, float2* out, float* phase, const BandBank* bank,
                              float* feat, const float* offset, const float* scale, float eps, int contrast, int power2,
                              int feat_channel_major, hipStream_t stream, const PolarOut* polar, int hop) {
-  if (hop != 256 && (bank || (hop != 128 && hop != 512))) return -1;   // the fused epilogues are built for hop 256
+  if (hop != 256 && hop != 128 && hop != 512) return -1;
+  // at hop 128 / 512 the fused epilogue exists in its two plain forms (spectrum + features, features only); the
+  // channel-major (MFCC) and Polar variants are built for the reference's hop 256
+  if (hop != 256 && bank && (polar || feat_channel_major)) return -1;
   FwdRunParams p = {};
   p.x = x; p.window = window; p.tw = tw; p.out = out; p.phase = phase;
   p.B = B; p.L = L; p.clip_stride = clip_stride; p.T = T;
@@ -875,6 +878,13 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     else if (!out && polar) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, true>;
     else if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true>;
     else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true> : stft1024_h256_fwd_kernel<false, 1, 8, true>;
+    if (hop == 128) {
+      if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 1>;
+      else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true, 0, false, 1> : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 1>;
+    } else if (hop == 512) {
+      if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 4>;
+      else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true, 0, false, 4> : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 4>;
+    }
   }
   // runs of at least 24 frames so that the extra segment loads of a run start stay < 5 % (counted as
   // 1024 / hop - 3 >= 1 frames of overhead per run)

@@ -438,19 +438,20 @@ def griffinlim_update(mag, rebuilt, tprev, momentum_over_1p):
 
 
 def stft_mel_forward(x, window, band, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1,
-                     want_spectrum=True, want_phase=False, channel_major=False):
-    """Fused n_fft=1024 / hop=256 forward: x (B, L) -> (X (B,T,513) complex64 or None, phase or None, features).
-    `band` is a utils.banded.BandedBank (eligible).  features: (B, T, N), or (B, N, T) when channel_major."""
+                     want_spectrum=True, want_phase=False, channel_major=False, hop=256):
+    """Fused n_fft=1024 forward (hop 256; 128 / 512 without channel_major): x (B, L) -> (X (B,T,513) complex64 or
+    None, phase or None, features).  `band` is a utils.banded.BandedBank (eligible).  features: (B, T, N), or
+    (B, N, T) when channel_major."""
     require_device(x, window)
     x = _f32c(x)
     B, L = x.shape
-    T = 1 + L // 256
+    T = 1 + L // hop
     lane_filter, lane_start, weights = band.on(x.device)
     N = band.N
     X = torch.empty((B, T, 513), dtype=torch.complex64, device=x.device) if want_spectrum else None
     phase = torch.empty((B, T, 513), dtype=torch.float32, device=x.device) if (want_phase and want_spectrum) else None
     feat = torch.empty((B, N, T) if channel_major else (B, T, N), dtype=torch.float32, device=x.device)
-    check(lib().at_stft_mel_forward(ptr(x), B, L, L, T, 1024, 256, ptr(window), ptr(lane_filter), ptr(lane_start),
+    check(lib().at_stft_mel_forward(ptr(x), B, L, L, T, 1024, hop, ptr(window), ptr(lane_filter), ptr(lane_start),
                                     ptr(weights), N, band.n_passes, band.pass_len.ctypes.data,
                                     contrast_code(contrast), int(power == 2),
                                     ptr(offset), ptr(scale), eps, ptr(X), ptr(phase), ptr(feat), int(channel_major),

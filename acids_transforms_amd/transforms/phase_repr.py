@@ -218,7 +218,7 @@ class SpectralRepresentation(AudioTransform):
         if not (type(mag) is Magnitude and type(ph) is Phase and self.stack == -2 and mag.keep_nyquist
                 and ph.keep_nyquist and not ph.unwrap):
             return False
-        if not mag.can_fuse_with(stage, x):
+        if not mag.can_fuse_with(stage, x) or stage._hop != 256:      # the STFT+Polar kernel is built for hop 256
             return False
         band = mag._banded()
         return band is not None and band.N == 513

@@ -103,13 +103,13 @@ class Magnitude(AudioTransform):
         return self._band_of("mel_bank")
 
     def can_fuse_with(self, stage, x: torch.Tensor) -> bool:
-        """True when `stage` (an offline STFT/DGT with n_fft=1024, hop=256) followed by this module can run
-        as the single fused kernel on input x."""
+        """True when `stage` (an offline STFT/DGT with n_fft=1024 and hop 256, 128 or 512) followed by this module can
+        run as the single fused kernel on input x."""
         from .stft import STFT, RealtimeSTFT
         from .dgt import RealtimeDGT
         if not isinstance(stage, STFT) or isinstance(stage, (RealtimeSTFT, RealtimeDGT)):
             return False
-        if stage._n_fft != 1024 or stage._hop != 256 or not x.is_cuda or x.dtype != torch.float32:
+        if stage._n_fft != 1024 or stage._hop not in (128, 256, 512) or not x.is_cuda or x.dtype != torch.float32:
             return False
         if x.shape[-1] <= 512 or (x.shape[-1] & 1):
             return False
@@ -125,7 +125,7 @@ class Magnitude(AudioTransform):
         off, sc = self._affine()
         xb, batch_shape = reshape_batches(x, -1)
         X, phase, feat = ops.stft_mel_forward(xb, stage.window[:1024], self._banded(), self.contrast_mode, off, sc,
-                                              self._eps, want_phase=stage.eager_phase)
+                                              self._eps, want_phase=stage.eager_phase, hop=stage._hop)
         stage._replace_phase_buffer(X, phase)
         feat = feat.reshape(batch_shape + feat.shape[-2:])
         if return_spectrum:

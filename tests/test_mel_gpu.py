@@ -339,3 +339,31 @@ def test_small_projection_shapes(dev):
     big = torch.randn(4, 10, 200, generator=gen)           # K > 128: the MFMA contraction takes over
     Wb = torch.randn(200, 30, generator=gen)
     assert rel_max(cpu(ops.mel_forward_real(big.to(dev), Wb.to(dev))), (big @ Wb).numpy()) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop", [128, 512])
+def test_fused_stft_mel_at_other_hops(dev, hop):
+    """Compose(STFT|DGT(hop=128 | 512) + Magnitude) is still one kernel (sliding window of 1 or 4 register slots per
+    frame + the banded epilogue): same features as stage by stage and as the oracle; Polar falls back to stages."""
+    g = torch.Generator().manual_seed(hop)
+    x = torch.randn(5, 30000, generator=g) * 0.1
+    xd = x.to(dev)
+    for cls in (A.STFT, A.DGT):
+        st, mg = cls(hop_length=hop).to(dev), A.Magnitude(n_mels=128).to(dev)
+        comp = st + mg
+        comp.scale_data(xd)
+        assert mg.can_fuse_with(st, xd)
+        y = comp(xd)
+        X = st(xd)
+        assert y.shape == (5, 1 + 30000 // hop, 128)
+        assert rel_max(cpu(y), cpu(mg(X))) < TOL
+        Xr = O.stft_forward(x, st.window[:1024].cpu(), 1024, hop)
+        fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100))
+        off, sc = O.magnitude_scale_stats(Xr, "log1p", "unipolar")
+        assert rel_max(cpu(y), O.magnitude_forward(Xr, fwd, "log1p", off, sc).numpy()) < TOL
+        Xf, feat = mg.forward_fused(st, xd, return_spectrum=True)
+        assert rel_max(cpu(Xf), Xr.numpy()) < TOL and torch.equal(feat, y)
+    pol = A.Polar().to(dev)
+    pol.scale_data(A.STFT(hop_length=hop).to(dev)(xd))
+    assert not pol.can_fuse_with(A.STFT(hop_length=hop).to(dev), xd)
