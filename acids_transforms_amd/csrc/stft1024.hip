@@ -109,23 +109,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void stft1024_fwd_kernel(FwdP
     // software prefetch of this wave's next frame
     if (f + WAVES_PER_BLOCK < f_end) load_frame(p, f + WAVES_PER_BLOCK, lane, nxt);
 
-#if !defined(AT_ABLATE) || AT_ABLATE != 1
     fft512<false>(v, tw, lds, lane);
     float2 nyq;
     rfft_merge(v, tw, lane, nyq);
-#else
-    float2 nyq = v[0];
-#endif
 
     float2* row = p.out + f * F;
-#if defined(AT_ABLATE) && AT_ABLATE == 2
-    if (v[0].x == 123456.789f && v[3].y == 2.5f)
-#endif
-    {
 #pragma unroll
     for (int m = 0; m < 8; ++m) row[lane + 64 * m] = v[m];
     if (lane == 0) row[512] = nyq;
-    }
     if (WRITE_PHASE) {
       float* prow = p.phase + f * F;
 #pragma unroll
