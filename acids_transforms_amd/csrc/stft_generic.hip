@@ -16,6 +16,7 @@ struct GenFwdParams {
   float* phase;
   long long B, L, clip_stride, T;
   int n_fft, hop, center;
+  int use_tw;   // the twiddle table fits in LDS
 };
 
 __device__ __forceinline__ long long g_reflect(long long i, long long L) {
@@ -28,14 +29,31 @@ __device__ __forceinline__ float2 g_cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// tw[j] = exp(sign * 2 pi i j / M), j < M / 2: every stage's twiddle exp(sign * i pi k / Ns) is entry k * M / (2 Ns) --
+// the same sincospif argument (k / Ns = 2 j / M exactly), evaluated once per workgroup instead of once per butterfly.
+__device__ void fill_twiddles(float2* tw, int M, float sign) {
+  for (int j = threadIdx.x; j < M / 2; j += blockDim.x) {
+    float s, c;
+    sincospif(sign * 2.0f * (float)j / (float)M, &s, &c);
+    tw[j] = make_float2(c, s);
+  }
+}
+
 // Stockham radix-2 autosort FFT of M points held in `a` (ping) with scratch `b`.
-// Returns the pointer that holds the result.  sign = -1 forward, +1 inverse.
-__device__ float2* stockham(float2* a, float2* b, int M, float sign) {
+// Returns the pointer that holds the result.  sign = -1 forward, +1 inverse.  tw: fill_twiddles table or null.
+__device__ float2* stockham(float2* a, float2* b, int M, float sign, const float2* tw) {
   for (int Ns = 1; Ns < M; Ns <<= 1) {
+    const int tstep = (M / 2) / Ns;
     for (int j = threadIdx.x; j < M / 2; j += blockDim.x) {
       int k = j & (Ns - 1);
       float s, c;
-      sincospif(sign * (float)k / (float)Ns, &s, &c);  // angle = sign * 2*pi*k/(2 Ns)
+      if (tw) {
+        const float2 w = tw[k * tstep];
+        c = w.x;
+        s = w.y;
+      } else {
+        sincospif(sign * (float)k / (float)Ns, &s, &c);  // angle = sign * 2*pi*k/(2 Ns)
+      }
       float2 u = a[j];
       float2 v = g_cmul(a[j + M / 2], make_float2(c, s));
       int j0 = ((j - k) << 1) + k;
@@ -55,6 +73,8 @@ __global__ void rfft_generic_kernel(GenFwdParams p) {
   const int Nf = p.n_fft, M = Nf / 2;
   float2* a = sm;
   float2* b = sm + M;
+  float2* tw = p.use_tw ? sm + 2 * M : nullptr;
+  if (tw) fill_twiddles(tw, M, -1.0f);
   const long long f = blockIdx.x;
   const long long bidx = f / p.T, t = f - bidx * p.T;
   const float* clip = p.x + bidx * p.clip_stride;
@@ -72,7 +92,7 @@ __global__ void rfft_generic_kernel(GenFwdParams p) {
     a[n] = make_float2(x0 * p.window[2 * n], x1 * p.window[2 * n + 1]);
   }
   __syncthreads();
-  float2* Z = stockham(a, b, M, -1.0f);
+  float2* Z = stockham(a, b, M, -1.0f, tw);
   const int Fb = M + 1;
   float2* row = p.out + f * Fb;
   float* prow = p.phase ? p.phase + f * Fb : nullptr;
@@ -99,6 +119,7 @@ struct GenInvParams {
   const float* window;
   float* frames;  // (B*T, n_fft)
   int n_fft;
+  int use_tw;
 };
 
 __global__ void irfft_generic_kernel(GenInvParams p) {
@@ -107,6 +128,8 @@ __global__ void irfft_generic_kernel(GenInvParams p) {
   float2* a = sm;
   float2* b = sm + M;
   float2* xs = sm + 2 * M;  // staged spectrum, Fb entries
+  float2* tw = p.use_tw ? xs + Fb + 1 : nullptr;
+  if (tw) fill_twiddles(tw, M, +1.0f);
   const long long f = blockIdx.x;
   for (int k = threadIdx.x; k <= M; k += blockDim.x) {
     float2 v;
@@ -133,7 +156,7 @@ __global__ void irfft_generic_kernel(GenInvParams p) {
     a[k] = make_float2(e.x - d.y, e.y + d.x);
   }
   __syncthreads();
-  float2* z = stockham(a, b, M, +1.0f);
+  float2* z = stockham(a, b, M, +1.0f, tw);
   const float sc = 1.0f / (float)Nf;
   float2* dst = reinterpret_cast<float2*>(p.frames + f * Nf);
   for (int n = threadIdx.x; n < M; n += blockDim.x)
@@ -182,8 +205,9 @@ static int set_lds(const void* fn, size_t bytes) {
 int launch_rfft_generic(const float* x, long long B, long long L, long long clip_stride, long long T, int n_fft,
                         int hop, int center, const float* window, float2* out, float* phase, hipStream_t stream) {
   if (B * T == 0) return 0;
-  GenFwdParams p = {x, window, out, phase, B, L, clip_stride, T, n_fft, hop, center};
-  size_t lds = sizeof(float2) * (size_t)n_fft;  // 2 * M
+  const int use_tw = n_fft <= 4096;
+  GenFwdParams p = {x, window, out, phase, B, L, clip_stride, T, n_fft, hop, center, use_tw};
+  size_t lds = sizeof(float2) * (size_t)(n_fft + (use_tw ? n_fft / 4 : 0));  // 2 * M (+ M / 2 twiddles)
   if (set_lds((const void*)rfft_generic_kernel, lds)) return -5;
   int threads = n_fft / 4 < 64 ? 64 : (n_fft / 4 > 256 ? 256 : n_fft / 4);
   hipLaunchKernelGGL(rfft_generic_kernel, dim3((unsigned)(B * T)), dim3(threads), lds, stream, p);
@@ -193,8 +217,9 @@ int launch_rfft_generic(const float* x, long long B, long long L, long long clip
 int launch_irfft_generic(const float2* X, const float* mag, const float* phase, long long nframes, int n_fft,
                          const float* window, float* frames, hipStream_t stream) {
   if (nframes == 0) return 0;
-  GenInvParams p = {X, mag, phase, window, frames, n_fft};
-  size_t lds = sizeof(float2) * (size_t)(n_fft + n_fft / 2 + 2);
+  const int use_tw = n_fft <= 4096;
+  GenInvParams p = {X, mag, phase, window, frames, n_fft, use_tw};
+  size_t lds = sizeof(float2) * (size_t)(n_fft + n_fft / 2 + 2 + (use_tw ? n_fft / 4 : 0));
   if (set_lds((const void*)irfft_generic_kernel, lds)) return -5;
   int threads = n_fft / 4 < 64 ? 64 : (n_fft / 4 > 256 ? 256 : n_fft / 4);
   hipLaunchKernelGGL(irfft_generic_kernel, dim3((unsigned)nframes), dim3(threads), lds, stream, p);
