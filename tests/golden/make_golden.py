@@ -622,9 +622,33 @@ def g13():
     save("g13_sinebank", **out)
 
 
+# --------------------------------------------------------------------------
+# G14: n_fft = 1024 at hop 128 and 512 (the other hops of the sliding kernels): STFT / DGT forward, complex
+# inverse, the hop-dependent DGT dual window, and a short offline PGHI reconstruction at hop 128
+# --------------------------------------------------------------------------
+def g14():
+    x = torch.stack([sig_noise((3000,), 14), sig_tonal(3000)])
+    out = {"x": x}
+    for name, cls in [("stft", at.STFT), ("dgt", at.DGT)]:
+        for h in (128, 512):
+            m = cls(n_fft=1024, hop_length=h)
+            X = m(x)
+            key = "%s_%d" % (name, h)
+            out["X_" + key] = X
+            out["y_" + key] = m.invert(X)
+            out["inv_window_" + key] = m.inv_window[:1024]
+    d = at.DGT(n_fft=1024, hop_length=128)
+    xs = sig_tonal(1500)[None]
+    mag = d(xs).abs()
+    out["pghi_mag"] = mag
+    out["pghi_y"] = d.invert(mag, inversion_mode="pghi")
+    save("g14_other_hops", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13"]
-    table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14"]
+    table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13,
+             "g14": g14}
     for w in which:
         print("==", w)
         table[w]()

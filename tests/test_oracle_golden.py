@@ -43,6 +43,21 @@ def test_stft_istft(golden, name, n, h):
     assert rel_max(y.numpy(), g["y_" + k]) < 3e-6
 
 
+@pytest.mark.parametrize("name,h", [("stft", 128), ("stft", 512), ("dgt", 128), ("dgt", 512)])
+def test_stft_istft_other_hops(golden, name, h):
+    """G14: the reference itself at n_fft = 1024, hop 128 / 512 (the hop-dependent DGT dual window included)."""
+    g = golden("g14_other_hops")
+    x = T(g["x"])
+    w = O.hann_window(1024) if name == "stft" else O.gauss_window(1024)
+    iw = w if name == "stft" else O.dual_window(w, 1024, h)
+    k = "%s_%d" % (name, h)
+    assert rel_max(iw.numpy(), g["inv_window_" + k]) < 1e-6
+    X = O.stft_forward(x, w, 1024, h)
+    assert X.shape == g["X_" + k].shape and rel_max(X.numpy(), g["X_" + k]) < 3e-6
+    y = O.istft(X, iw, 1024, h)
+    assert y.shape == g["y_" + k].shape and rel_max(y.numpy(), g["y_" + k]) < 3e-6
+
+
 def test_stft_multidim_and_time(golden):
     g = golden("g2_stft")
     x = T(g["x_md"])

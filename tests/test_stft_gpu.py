@@ -242,3 +242,25 @@ def test_other_hops_take_the_sliding_kernels(dev, hop):
     # polar input to the fused inverse
     yp = ops.istft(None, st.inv_window[:1024], 1024, hop, env16=st._env16, mag=Xb.abs(), phase=Xb.angle())
     assert rel_max(yp.cpu().numpy(), st.invert(Xb).cpu().numpy()) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,h", [("stft", 128), ("stft", 512), ("dgt", 128), ("dgt", 512)])
+def test_other_hops_golden(golden, dev, name, h):
+    """G14: outputs of the reference itself at n_fft = 1024, hop 128 / 512 -- forward, complex inverse, the DGT dual
+    window, and a PGHI reconstruction at hop 128."""
+    g = golden("g14_other_hops")
+    m = (A.STFT if name == "stft" else A.DGT)(n_fft=1024, hop_length=h).to(dev)
+    k = "%s_%d" % (name, h)
+    x = torch.from_numpy(g["x"]).to(dev)
+    assert rel_max(cpu(m.inv_window[:1024]), g["inv_window_" + k]) < 1e-6
+    X = m(x)
+    assert X.shape == g["X_" + k].shape and rel_max(cpu(X), g["X_" + k]) < TOL
+    y = m.invert(torch.from_numpy(g["X_" + k]).to(dev))
+    assert y.shape == g["y_" + k].shape and rel_max(cpu(y), g["y_" + k]) < TOL
+    if name == "dgt" and h == 128:
+        yp = m.invert(torch.from_numpy(g["pghi_mag"]).to(dev), inversion_mode="pghi")
+        ref = g["pghi_y"]
+        assert yp.shape == ref.shape
+        err = cpu(yp) - ref
+        assert 10 * np.log10((ref ** 2).sum() / max((err ** 2).sum(), 1e-30)) >= 40.0     # same bar as the hop-256 cases
