@@ -250,8 +250,10 @@ def main():
         except Exception as exc:
             extras[name + "_error"] = repr(exc)[:300]
 
-    def extra_allgather():
+    def extra_allgather(wire_dtype=None):
         # features reassembled on every rank with one RCCL all-gather on a side stream, overlapped with the next step
+        # (wire_dtype=torch.bfloat16: the shard is cast on the side stream first -- half the bytes over xGMI; the
+        # features computed and kept on the owning rank stay fp32)
         from acids_transforms_amd.dist import all_gather_features
         comm = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize()
@@ -267,7 +269,8 @@ def main():
             with torch.cuda.stream(comm):
                 comm.wait_event(done)
                 feat.record_stream(comm)
-                _, pending = all_gather_features(feat, world * B, async_op=True)
+                wire = feat if wire_dtype is None else feat.to(wire_dtype)
+                _, pending = all_gather_features(wire, world * B, async_op=True)
         if pending is not None:
             pending.wait()
         torch.cuda.synchronize()
@@ -430,6 +433,7 @@ def main():
             guarded("mfcc40_forward", extra_mfcc40)
         if world > 1 and not rehearsal:
             guarded("with_feature_allgather_frames_per_s", extra_allgather)
+            guarded("with_feature_allgather_bf16_wire_frames_per_s", lambda: extra_allgather(torch.bfloat16))
         if rank == 0 and args.pghi_clips > 0:
             guarded("pghi_invert", extra_pghi)
         if rank == 0 and args.streams > 0:
