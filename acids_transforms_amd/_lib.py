@@ -57,6 +57,7 @@ _SIGNATURES = {
                          c_f, c_sz, c_f],
     "at_rt_update_buffers": [c_f, c_f, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_griffinlim_update": [c_f, c_f, c_f, c_flt, c_i64, c_f, c_f],
+    "at_istft_griffinlim": [c_f, c_f, c_f, c_flt, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_scale_complex": [c_f, c_f, c_i64, c_f, c_f],
     "at_oadd_forward": [c_f, c_f, c_int, c_i64, c_int, c_i64, c_f, c_f, c_f],
     "at_oadd_invert": [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f],

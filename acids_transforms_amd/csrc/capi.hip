@@ -16,7 +16,8 @@ int launch_stft1024_h256_fwd(const float*, long long, long long, long long, long
                              float2*, float*, const BandBank*, float*, const float*, const float*, float, int, int, int,
                              hipStream_t, const PolarOut* polar = nullptr, int hop = 256);
 int launch_istft1024_ola(const float2*, const float*, const float*, long long, long long, int, const float*,
-                         const float*, const float2*, float*, hipStream_t);
+                         const float*, const float2*, float*, hipStream_t, const float2* gl_tprev = nullptr,
+                         float gl_mom = 0.f);
 int launch_irfft1024_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
                             float*, hipStream_t);
 // stft_generic.hip
@@ -218,6 +219,22 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
   int rc = launch_irfft_generic((const float2*)X_complex, mag, phase, B * T, n_fft, inv_window, (float*)workspace, s);
   if (rc) return rc;
   return launch_ola_gather((const float*)workspace, B, T, n_fft, hop, inv_window, y, s);
+}
+
+int at_istft_griffinlim(const float* mag, const float* rebuilt_complex, const float* tprev_complex_or_null,
+                        float momentum_over_1p, int64_t B, int64_t T, int n_fft, int hop, const float* inv_window,
+                        const float* env16, float* y, void* stream) {
+  if (B < 0 || T < 0 || hop <= 0 || n_fft <= 0) return AT_EINVAL;
+  if (B == 0 || T <= 1) return AT_OK;
+  if (!mag || !rebuilt_complex || !inv_window || !y) return AT_EINVAL;
+  if (!istft_fast(n_fft, hop, env16, inv_window) || (((uintptr_t)y) & 7)) return AT_EUNSUPPORTED;
+  const float2* tw = twiddles_for_current_device();
+  if (!tw) return AT_ENOTINIT;
+  // first iteration (no previous spectrum): momentum 0 against the rebuilt spectrum itself
+  const float2* tprev = tprev_complex_or_null ? (const float2*)tprev_complex_or_null : (const float2*)rebuilt_complex;
+  const float mom = tprev_complex_or_null ? momentum_over_1p : 0.0f;
+  return launch_istft1024_ola((const float2*)rebuilt_complex, mag, nullptr, B, T, hop, inv_window, env16, tw, y,
+                              (hipStream_t)stream, tprev, mom);
 }
 
 int at_irfft_frames(const float* X_complex, const float* mag, const float* phase, int64_t nframes, int n_fft,

@@ -454,13 +454,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
 // ---------------------------------------------------------------------------
 // inverse
 // ---------------------------------------------------------------------------
-enum { IN_COMPLEX = 0, IN_POLAR = 1 };
+enum { IN_COMPLEX = 0, IN_POLAR = 1, IN_GL = 2 };
 enum { OUT_OLA = 0, OUT_FRAMES = 1 };
 
 struct InvParams {
   const float2* X;      // (B*T, 513) complex64           (IN_COMPLEX)
   const float* mag;     // (B*T, 513)                      (IN_POLAR)
   const float* phase;   // (B*T, 513)                      (IN_POLAR)
+  const float2* tprev;  // (B*T, 513) complex64           (IN_GL: X = the rebuilt spectrum, mag = the target magnitudes)
+  float gl_mom;         // IN_GL: momentum / (1 + momentum)
   const float* window;  // N synthesis window samples
   const float* env;     // OUT_OLA: 16 x hop table, env[mask][r] = sum of window^2 over the frames in mask
   const float2* tw;
@@ -498,6 +500,15 @@ struct RawFrame<IN_POLAR> {
   float a[8], ph[8];
   float ny0, ny1;
 };
+// IN_GL: the Griffin-Lim phase update (torchaudio.functional.griffinlim as called at reference stft.py:174-178)
+// taken at load time -- X = mag * normalise(rebuilt - m' tprev) never exists in HBM
+template <>
+struct RawFrame<IN_GL> {
+  f32x2 r[8], t[8];
+  float a[8];
+  f32x2 rny, tny;
+  float any;
+};
 
 __device__ __forceinline__ void load_raw(const InvParams& p, long long f, int lane, RawFrame<IN_COMPLEX>& q) {
   const f32x2* row = reinterpret_cast<const f32x2*>(p.X + f * F);
@@ -517,6 +528,33 @@ __device__ __forceinline__ void load_raw(const InvParams& p, long long f, int la
   q.ny1 = prow[512];
 }
 
+__device__ __forceinline__ void load_raw(const InvParams& p, long long f, int lane, RawFrame<IN_GL>& q) {
+  const f32x2* rrow = reinterpret_cast<const f32x2*>(p.X + f * F);
+  const f32x2* trow = reinterpret_cast<const f32x2*>(p.tprev + f * F);
+  const float* mrow = p.mag + f * F;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    q.r[m] = rrow[lane + 64 * m];
+    q.t[m] = trow[lane + 64 * m];
+    q.a[m] = mrow[lane + 64 * m];
+  }
+  q.rny = rrow[512];
+  q.tny = trow[512];
+  q.any = mrow[512];
+}
+
+__device__ __forceinline__ float2 gl_update(f32x2 r, f32x2 t, float mag, float mom) {
+  float ax = r.x, ay = r.y;
+  ax -= mom * t.x;
+  ay -= mom * t.y;
+  // |a| + 1e-16 and the two quotients through the hardware sqrt / rcp (1 ulp each): this runs 513 times per frame
+  // in front of the FFT, where libm's hypotf and two IEEE divisions (~50 instructions) made the kernel VALU-bound.
+  // Audio-scale spectra are nowhere near the range where hypot's rescaling matters.
+  const float d = __builtin_amdgcn_sqrtf(fmaf(ax, ax, ay * ay)) + 1e-16f;
+  const float s = mag * __builtin_amdgcn_rcpf(d);
+  return make_float2(s * ax, s * ay);
+}
+
 __device__ __forceinline__ void raw_to_spectrum(const RawFrame<IN_COMPLEX>& q, float2 (&v)[8], float& nyq_re) {
 #pragma unroll
   for (int m = 0; m < 8; ++m) v[m] = make_float2(q.d[m].x, q.d[m].y);
@@ -532,6 +570,12 @@ __device__ __forceinline__ void raw_to_spectrum(const RawFrame<IN_POLAR>& q, flo
   float sn, cs;
   sincos_big(q.ny1, sn, cs);
   nyq_re = q.ny0 * cs;
+}
+
+__device__ __forceinline__ void raw_to_spectrum(const RawFrame<IN_GL>& q, float2 (&v)[8], float& nyq_re, float mom) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = gl_update(q.r[m], q.t[m], q.a[m], mom);
+  nyq_re = gl_update(q.rny, q.tny, q.any, mom).x;
 }
 
 template <int IN_MODE>
@@ -572,7 +616,7 @@ __device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const 
 // and the previous outputs' stores in flight across iterations (a conditional load anywhere in the loop
 // collapses every wait to vmcnt(0)).
 template <int IN_MODE, int DEPTH, bool TWLDS, int HS = 2>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void istft1024_ola_kernel(InvParams p) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS ? 5 : 4) - DEPTH) void istft1024_ola_kernel(InvParams p) {
   constexpr int R = 8 / HS;          // overlapping frames
   constexpr int C = 4 / HS;          // centre trim in hops
   constexpr int H = 128 * HS;        // hop in samples
@@ -624,7 +668,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, (TWLDS ? 5 : 4) - DEPTH) void
   auto consume = [&](const RawFrame<IN_MODE>& q) {
     float2 v[8];
     float nyq;
-    raw_to_spectrum(q, v, nyq);
+    if constexpr (IN_MODE == IN_GL) raw_to_spectrum(q, v, nyq, p.gl_mom);
+    else raw_to_spectrum(q, v, nyq);
     synth(v, nyq);
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc[m] = cadd(acc[m], v[m]);
@@ -889,9 +934,11 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
 }
 
 int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, long long B, long long T, int hop,
-                         const float* window, const float* env16, const float2* tw, float* y, hipStream_t stream) {
+                         const float* window, const float* env16, const float2* tw, float* y, hipStream_t stream,
+                         const float2* gl_tprev, float gl_mom) {
   InvParams p = {};
   p.X = X; p.mag = mag; p.phase = phase; p.window = window; p.env = env16; p.tw = tw; p.y = y;
+  p.tprev = gl_tprev; p.gl_mom = gl_mom;
   p.B = B; p.T = T;
   const long long nslots = T - 1;
   if (B == 0 || nslots <= 0) return 0;
@@ -902,6 +949,11 @@ int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, 
   else if (hop == 256) kernel = X ? istft1024_ola_kernel<IN_COMPLEX, 2, false, 2> : istft1024_ola_kernel<IN_POLAR, 2, false, 2>;
   else if (hop == 512) kernel = X ? istft1024_ola_kernel<IN_COMPLEX, 2, false, 4> : istft1024_ola_kernel<IN_POLAR, 2, false, 4>;
   else return -1;
+  if (gl_tprev) {   // Griffin-Lim update at load time: X = rebuilt, mag = target magnitudes; one frame in flight (40 VGPRs each)
+    if (!X || !mag) return -1;
+    kernel = hop == 128 ? istft1024_ola_kernel<IN_GL, 1, true, 1>
+           : hop == 256 ? istft1024_ola_kernel<IN_GL, 1, true, 2> : istft1024_ola_kernel<IN_GL, 1, true, 4>;
+  }
   // runs of >= 32 hop slots: a run synthesises n_fft/hop - 1 frames more than it emits slots
   const long long slots = resident_waves(kernel, 64 * WAVES_PER_BLOCK, 0);
   const long long spr = plan_units_per_run(B, nslots, slots, 32, 1024 / hop - 1);

@@ -437,6 +437,17 @@ def griffinlim_update(mag, rebuilt, tprev, momentum_over_1p):
     return out
 
 
+def istft_griffinlim(mag, rebuilt, tprev, momentum_over_1p, inv_window, n_fft, hop, env16):
+    """istft(griffinlim_update(mag, rebuilt, tprev, m)) in one kernel (n_fft 1024, hop 128 / 256 / 512)."""
+    require_device(mag, rebuilt, inv_window, env16)
+    mag = _f32c(mag)
+    B, T, F = mag.shape
+    y = torch.empty((B, hop * max(T - 1, 0)), dtype=torch.float32, device=mag.device)
+    check(lib().at_istft_griffinlim(ptr(mag), ptr(rebuilt), ptr(tprev), momentum_over_1p, B, T, n_fft, hop,
+                                    ptr(inv_window), ptr(env16), ptr(y), stream_ptr()), "at_istft_griffinlim")
+    return y
+
+
 def stft_mel_forward(x, window, band, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1,
                      want_spectrum=True, want_phase=False, channel_major=False, hop=256):
     """Fused n_fft=1024 forward (hop 256; 128 / 512 without channel_major): x (B, L) -> (X (B,T,513) complex64 or

@@ -279,6 +279,15 @@ class STFT(AudioTransform):
         env = self._env16 if self._env16.numel() else None
         X = ops.scale_complex(x, angles0)
         tprev = None
+        if n == 1024 and h in (128, 256, 512) and env is not None and x.dim() == 3:
+            # every inverse after the first is istft(update(...)): one kernel, the updated spectrum is never written
+            inverse = ops.istft(X, window, n, h, env16=env)
+            del X
+            for _ in range(n_iter):
+                rebuilt = ops.stft_forward(inverse, window, n, h, center=True)
+                inverse = ops.istft_griffinlim(x, rebuilt, tprev, m, window, n, h, env)
+                tprev = rebuilt
+            return inverse
         for _ in range(n_iter):
             inverse = ops.istft(X, window, n, h, env16=env)
             rebuilt = ops.stft_forward(inverse, window, n, h, center=True)

@@ -187,6 +187,12 @@ int at_angle(const float *x_complex, int64_t n, float *out, void *stream);
  * X = mag * a / (|a| + 1e-16), with m = momentum / (1 + momentum).  n complex elements. */
 int at_griffinlim_update(const float *mag, const float *rebuilt_complex, const float *tprev_complex_or_null,
                          float momentum_over_1p, int64_t n, float *X_complex, void *stream);
+/* The same update fused into the inverse: at_istft(mag * normalise(rebuilt - m' * tprev)) in one kernel, the updated
+ * spectrum never written (one Griffin-Lim iteration = this + at_stft_forward).  n_fft = 1024, hop 128 / 256 / 512 with
+ * env16 from at_istft_envelope_table; anything else: AT_EUNSUPPORTED (use at_griffinlim_update + at_istft). */
+int at_istft_griffinlim(const float *mag, const float *rebuilt_complex, const float *tprev_complex_or_null,
+                        float momentum_over_1p, int64_t B, int64_t T, int n_fft, int hop, const float *inv_window,
+                        const float *env16, float *y, void *stream);
 /* X = mag * z (z complex): the random initialisation of the same algorithm. */
 int at_scale_complex(const float *mag, const float *z_complex, int64_t n, float *X_complex, void *stream);
 

@@ -264,3 +264,34 @@ def test_other_hops_golden(golden, dev, name, h):
         assert yp.shape == ref.shape
         err = cpu(yp) - ref
         assert 10 * np.log10((ref ** 2).sum() / max((err ** 2).sum(), 1e-30)) >= 40.0     # same bar as the hop-256 cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop", [128, 256, 512])
+def test_griffinlim_update_fused_into_the_inverse(dev, hop):
+    """at_istft_griffinlim == at_istft(at_griffinlim_update(...)): the phase update taken while the inverse kernel
+    loads its frames (first iteration without, later ones with a previous spectrum), and the whole 30-iteration
+    inversion against the unfused composition from the same random start."""
+    from acids_transforms_amd import ops
+    torch.manual_seed(hop)
+    st = A.STFT(n_fft=1024, hop_length=hop).to(dev)
+    x = torch.randn(3, 20000, device=dev) * 0.1
+    mag = st(x).abs()
+    rebuilt = st(torch.randn(3, 20000, device=dev) * 0.1)
+    tprev = st(torch.randn(3, 20000, device=dev) * 0.1)
+    w, env = st.inv_window[:1024], st._env16
+    for tp in (None, tprev):
+        want = ops.istft(ops.griffinlim_update(mag, rebuilt, tp, 0.99 / 1.99), w, 1024, hop, env16=env)
+        got = ops.istft_griffinlim(mag, rebuilt, tp, 0.99 / 1.99, w, 1024, hop, env)
+        assert got.shape == want.shape and rel_max(cpu(got), cpu(want)) < TOL
+    angles0 = torch.rand(mag.shape, dtype=torch.complex64, device=dev)
+    y = st.griffin_lim(mag, n_iter=8, angles0=angles0)
+    X = ops.scale_complex(mag, angles0)
+    tp = None
+    for _ in range(8):
+        rb = ops.stft_forward(ops.istft(X, w, 1024, hop, env16=env), w, 1024, hop, center=True)
+        X = ops.griffinlim_update(mag, rb, tp, 0.99 / 1.99)
+        tp = rb
+    # eight iterations amplify the 1e-7 differences of a single step; at 50 % overlap (Hann envelope close to zero at
+    # the frame edges) the iteration is far less contractive
+    assert rel_max(cpu(y), cpu(ops.istft(X, w, 1024, hop, env16=env))) < (1e-4 if hop < 512 else 5e-3)
