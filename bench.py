@@ -425,10 +425,23 @@ def main():
             del Xh
         return res
 
+    def extra_griffin_lim():
+        # STFT's default inversion mode (stft.py:37, 174-178): 30 iterations of {forward, phase update + inverse}
+        m = stft(x).abs()
+        stft.invert(m)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        stft.invert(m)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        return {"seconds": dt, "frames_per_s": frames_per_step / dt, "iterations": 30,
+                "note": "phase update fused into the inverse kernel's load stage; ~11.6 GB of HBM traffic per iteration"}
+
     if not args.no_extras:
         if rank == 0:
             guarded("hbm_probe", extra_hbm_probe)
             guarded("other_hops", extra_other_hops)
+            guarded("griffin_lim_invert", extra_griffin_lim)
             guarded("phase_representations", extra_phase_repr)
             guarded("mfcc40_forward", extra_mfcc40)
         if world > 1 and not rehearsal:
