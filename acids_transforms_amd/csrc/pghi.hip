@@ -1080,7 +1080,9 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
   if (B < 0 || T <= 0 || F <= 0 || n_fft <= 0 || hop <= 0) return AT_EINVAL;
   if (B == 0) return AT_OK;
   if (!mag || !phase) return AT_EINVAL;
-  if ((long long)T * F > 0x7ffffff0LL) return AT_EUNSUPPORTED;
+  // heap positions are 32-bit and a bubble round addresses ((pos + 1) << 5) + 31; the frame / bin split of a bin
+  // index goes through fp32: both hold up to 2^26 bins per clip (12 minutes of audio at n_fft 1024, hop 256)
+  if ((long long)T * F > (1LL << 26) - 64) return AT_EUNSUPPORTED;
   if (!workspace || workspace_bytes < at_pghi_offline_workspace_bytes(B, T, F)) return AT_EWORKSPACE;
   const size_t n = (size_t)T * (size_t)F;
   float* spec = (float*)workspace;

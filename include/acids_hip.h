@@ -155,7 +155,9 @@ size_t at_pghi_offline_workspace_bytes(int64_t B, int T, int F);
  * the binary-heap order of utils/heapq.py:9-59.  abstol is both the clamp floor
  * and the "visited" marker (the reference passes eps for both, dgt.py:157-162).
  * phase: (B,T,F).  npops_or_null: (B) pops per clip.  order_or_null: (B, T*F)
- * row*F+col of every pop in order (parity tests). */
+ * row*F+col of every pop in order (parity tests).
+ * T * F <= 2^26 - 64 bins per clip (32-bit heap positions; 12 minutes of audio at the default sizes), else
+ * AT_EUNSUPPORTED. */
 int at_pghi_offline(const float *mag, int64_t B, int T, int F, float gamma, int n_fft, int hop, float tol,
                     float abstol, float *phase, void *workspace, size_t workspace_bytes, int64_t *npops_or_null,
                     int32_t *order_or_null, void *stream);
