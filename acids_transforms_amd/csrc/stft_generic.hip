@@ -32,16 +32,52 @@ __device__ __forceinline__ float2 g_cmul(float2 a, float2 b) {
 // tw[j] = exp(sign * 2 pi i j / M), j < M / 2: every stage's twiddle exp(sign * i pi k / Ns) is entry k * M / (2 Ns) --
 // the same sincospif argument (k / Ns = 2 j / M exactly), evaluated once per workgroup instead of once per butterfly.
 __device__ void fill_twiddles(float2* tw, int M, float sign) {
-  for (int j = threadIdx.x; j < M / 2; j += blockDim.x) {
+  for (int j = threadIdx.x; j < 3 * M / 4 + 1; j += blockDim.x) {       // radix-4 stages reach 3 k M / (4 Ns) < 3 M / 4
     float s, c;
     sincospif(sign * 2.0f * (float)j / (float)M, &s, &c);
     tw[j] = make_float2(c, s);
   }
 }
 
-// Stockham radix-2 autosort FFT of M points held in `a` (ping) with scratch `b`.
-// Returns the pointer that holds the result.  sign = -1 forward, +1 inverse.  tw: fill_twiddles table or null.
+// Stockham autosort FFT of M points held in `a` (ping) with scratch `b`.  Returns the pointer that holds the result.
+// sign = -1 forward, +1 inverse.  tw: fill_twiddles table (radix-4 stages, one radix-2 stage first when log2 M is
+// odd: half the LDS passes and barriers) or null (n_fft > 4096: radix-2 with sincospi per butterfly).
 __device__ float2* stockham(float2* a, float2* b, int M, float sign, const float2* tw) {
+  if (tw && M >= 4) {
+    int Ns = 1;
+    if (__popc(M - 1) & 1) {          // log2 M odd: one radix-2 stage (Ns = 1: all twiddles are 1)
+      for (int j = threadIdx.x; j < M / 2; j += blockDim.x) {
+        const float2 u = a[j], v = a[j + M / 2];
+        b[2 * j] = make_float2(u.x + v.x, u.y + v.y);
+        b[2 * j + 1] = make_float2(u.x - v.x, u.y - v.y);
+      }
+      __syncthreads();
+      float2* t = a; a = b; b = t;
+      Ns = 2;
+    }
+    for (; Ns < M; Ns <<= 2) {
+      const int tstep = (M / 4) / Ns;        // twiddle exp(sign 2 pi i r k / (4 Ns)) = tw[r k tstep]
+      for (int j = threadIdx.x; j < M / 4; j += blockDim.x) {
+        const int k = j & (Ns - 1);
+        const float2 v0 = a[j];
+        const float2 v1 = g_cmul(a[j + M / 4], tw[k * tstep]);
+        const float2 v2 = g_cmul(a[j + M / 2], tw[2 * k * tstep]);
+        const float2 v3 = g_cmul(a[j + 3 * M / 4], tw[3 * k * tstep]);
+        const float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y), d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
+        const float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y), d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
+        // sign * i * d13
+        const float2 r = make_float2(-sign * d13.y, sign * d13.x);
+        const int j0 = ((j - k) << 2) + k;
+        b[j0] = make_float2(s02.x + s13.x, s02.y + s13.y);
+        b[j0 + Ns] = make_float2(d02.x + r.x, d02.y + r.y);
+        b[j0 + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
+        b[j0 + 3 * Ns] = make_float2(d02.x - r.x, d02.y - r.y);
+      }
+      __syncthreads();
+      float2* t = a; a = b; b = t;
+    }
+    return a;
+  }
   for (int Ns = 1; Ns < M; Ns <<= 1) {
     const int tstep = (M / 2) / Ns;
     for (int j = threadIdx.x; j < M / 2; j += blockDim.x) {
@@ -126,9 +162,9 @@ __global__ void irfft_generic_kernel(GenInvParams p) {
   extern __shared__ __attribute__((aligned(16))) float2 sm[];
   const int Nf = p.n_fft, M = Nf / 2, Fb = M + 1;
   float2* a = sm;
-  float2* b = sm + M;
-  float2* xs = sm + 2 * M;  // staged spectrum, Fb entries
-  float2* tw = p.use_tw ? xs + Fb + 1 : nullptr;
+  float2* b = sm + M;       // M + 2 entries: until the FFT starts it stages the one-sided spectrum (Fb = M + 1)
+  float2* xs = b;
+  float2* tw = p.use_tw ? b + M + 2 : nullptr;
   if (tw) fill_twiddles(tw, M, +1.0f);
   const long long f = blockIdx.x;
   for (int k = threadIdx.x; k <= M; k += blockDim.x) {
@@ -207,7 +243,7 @@ int launch_rfft_generic(const float* x, long long B, long long L, long long clip
   if (B * T == 0) return 0;
   const int use_tw = n_fft <= 4096;
   GenFwdParams p = {x, window, out, phase, B, L, clip_stride, T, n_fft, hop, center, use_tw};
-  size_t lds = sizeof(float2) * (size_t)(n_fft + (use_tw ? n_fft / 4 : 0));  // 2 * M (+ M / 2 twiddles)
+  size_t lds = sizeof(float2) * (size_t)(n_fft + (use_tw ? 3 * n_fft / 8 + 1 : 0));  // 2 * M (+ 3 M / 4 + 1 twiddles)
   if (set_lds((const void*)rfft_generic_kernel, lds)) return -5;
   int threads = n_fft / 4 < 64 ? 64 : (n_fft / 4 > 256 ? 256 : n_fft / 4);
   hipLaunchKernelGGL(rfft_generic_kernel, dim3((unsigned)(B * T)), dim3(threads), lds, stream, p);
@@ -219,7 +255,7 @@ int launch_irfft_generic(const float2* X, const float* mag, const float* phase, 
   if (nframes == 0) return 0;
   const int use_tw = n_fft <= 4096;
   GenInvParams p = {X, mag, phase, window, frames, n_fft, use_tw};
-  size_t lds = sizeof(float2) * (size_t)(n_fft + n_fft / 2 + 2 + (use_tw ? n_fft / 4 : 0));
+  size_t lds = sizeof(float2) * (size_t)(n_fft + 2 + (use_tw ? 3 * n_fft / 8 + 1 : 0));   // a, b (+ twiddles)
   if (set_lds((const void*)irfft_generic_kernel, lds)) return -5;
   int threads = n_fft / 4 < 64 ? 64 : (n_fft / 4 > 256 ? 256 : n_fft / 4);
   hipLaunchKernelGGL(irfft_generic_kernel, dim3((unsigned)nframes), dim3(threads), lds, stream, p);

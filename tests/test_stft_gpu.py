@@ -295,3 +295,20 @@ def test_griffinlim_update_fused_into_the_inverse(dev, hop):
     # eight iterations amplify the 1e-7 differences of a single step; at 50 % overlap (Hann envelope close to zero at
     # the frame edges) the iteration is far less contractive
     assert rel_max(cpu(y), cpu(ops.istft(X, w, 1024, hop, env16=env))) < (1e-4 if hop < 512 else 5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 256, 512, 2048, 4096, 16384])
+def test_every_power_of_two_size(dev, n):
+    """The generic kernels (radix-4 / radix-2 Stockham in LDS) over the whole range the reference's window buffers
+    allow (stft.py:10 MAX_NFFT = 16384), hops n/8, n/4, n/2, STFT and DGT, forward and inverse against the oracle."""
+    for hop in (max(1, n // 8), n // 4, n // 2):
+        torch.manual_seed(n + hop)
+        x = torch.randn(2, max(3 * n, 2000)) * 0.1
+        for cls in (A.STFT, A.DGT):
+            t = cls(n_fft=n, hop_length=hop).to(dev)
+            X = t(x.to(dev))
+            Xr = O.stft_forward(x, t.window[:n].cpu(), n, hop)
+            assert X.shape == Xr.shape and rel_max(cpu(X), Xr.numpy()) < TOL, (hop, cls.__name__)
+            y, yr = t.invert(X), O.istft(Xr, t.inv_window[:n].cpu(), n, hop)
+            assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL, (hop, cls.__name__)
