@@ -1114,8 +1114,10 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
   } else {
     void (*kernel)(HgiParams) = prof ? pghi_hgi_offline_coop_kernel<true> : pghi_hgi_offline_coop_kernel<false>;
     if (heap_lds > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds) != hipSuccess)
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds) != hipSuccess) {
+      (void)hipGetLastError();
       return AT_ELAUNCH;
+    }
     hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(64), heap_lds, s, h);
   }
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;

@@ -233,7 +233,10 @@ __global__ void ola_gather_kernel(OlaParams p) {
 
 static int set_lds(const void* fn, size_t bytes) {
   if (bytes > 64 * 1024) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -5;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+      (void)hipGetLastError();   // do not leave the error latched for the next launch's check
+      return -5;
+    }
   }
   return 0;
 }
