@@ -367,3 +367,23 @@ def test_fused_stft_mel_at_other_hops(dev, hop):
     pol = A.Polar().to(dev)
     pol.scale_data(A.STFT(hop_length=hop).to(dev)(xd))
     assert not pol.can_fuse_with(A.STFT(hop_length=hop).to(dev), xd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft", [256, 2048, 4096])
+def test_magnitude_at_other_fft_sizes(dev, n_fft):
+    """Magnitude(n_fft != 1024): the reference-default F x F bank and an 80-mel one, forward and invert against the
+    oracle -- banded walk while a frame fits the LDS row (F <= 640), the dense MFMA projection above that."""
+    F = n_fft // 2 + 1
+    torch.manual_seed(n_fft)
+    X = (torch.randn(2, 9, F) + 1j * torch.randn(2, 9, F)).to(torch.complex64)
+    for kw in ({}, {"n_mels": 80}):
+        mg = A.Magnitude(n_fft=n_fft, **kw).to(dev)
+        mg.scale_data(X.to(dev))
+        assert (mg._band_of("mel_bank") is not None) == (F <= 640)
+        fwd, inv = O.magnitude_banks(O.melscale_fbanks(F, 0.0, 22050.0, kw.get("n_mels", F), 44100))
+        off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
+        yr = O.magnitude_forward(X, fwd, "log1p", off, sc)
+        y = mg(X.to(dev))
+        assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL
+        assert rel_max(cpu(mg.invert(y)), O.magnitude_invert(yr, inv, "log1p", off, sc).numpy()) < 2e-5
