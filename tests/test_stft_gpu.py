@@ -73,7 +73,10 @@ def test_keep_input_and_time_golden(golden, dev):
 @pytest.mark.parametrize("B,L,n,h", [(3, 5000, 1024, 256), (1, 1024, 1024, 256), (5, 2049, 1024, 256),
                                       (2, 7777, 1024, 128), (2, 7777, 1024, 512), (4, 4100, 256, 64),
                                       (2, 3000, 2048, 512), (3, 700, 64, 16), (1, 40000, 8192, 2048),
-                                      (2, 600, 32, 8), (1, 513, 1024, 256)])
+                                      (2, 600, 32, 8), (1, 513, 1024, 256),
+                                      # hops that do not divide n_fft (frame-at-a-time kernels, gather overlap-add)
+                                      (2, 9001, 1024, 100), (3, 6000, 1024, 300), (2, 5000, 1024, 1000),
+                                      (2, 8000, 1024, 1024), (2, 3001, 256, 100), (1, 30000, 2048, 441)])
 def test_vs_oracle_seeded(dev, B, L, n, h):
     g = torch.Generator().manual_seed(B * 1000 + L)
     x = torch.randn(B, L, generator=g)
