@@ -585,6 +585,7 @@ struct RtParams {
   HeapItem* heap;           // (S, 4F + 8)
   int S, n, F, n_fft, hop;
   float gamma, tol, eps;
+  int lds_floats_per_wave;  // cooperative kernel: LDS floats per stream (several streams per workgroup)
 };
 
 __device__ __forceinline__ float rt_mag(const RtParams& p, int s, int j, int k) {
@@ -850,12 +851,15 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_lds_kernel(RtParams p) {
 // whole heap in LDS.  A frame pops up to 2F entries from a heap of ~1000: done by one lane that is ~10 dependent
 // LDS round trips down and a few up per pop (~3600 cycles); the cooperative pop resolves five levels per round
 // with one wide LDS gather.  Same binary heap, same sift rules, same pop order.
-__global__ __launch_bounds__(64) void pghi_hgi_rt_coop_kernel(RtParams p) {
-  extern __shared__ __attribute__((aligned(16))) float rt_smem[];
-  const int s = blockIdx.x;
+__global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
+  extern __shared__ __attribute__((aligned(16))) float rt_smem_all[];
+  // one wave per stream, 1 to 4 independent waves per workgroup (see pghi_hgi_offline_coop_kernel)
+  const int wave = threadIdx.x >> 6;
+  const int s = blockIdx.x * (blockDim.x >> 6) + wave;
   if (s >= p.S) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int F = p.F, R = p.n + 2;
+  float* rt_smem = rt_smem_all + (size_t)wave * p.lds_floats_per_wave;
   const long long n = (long long)R * F;
   const float* spec = p.spec + (long long)s * n;
   const float* tgw = p.tgradw + (long long)s * n;
@@ -1161,8 +1165,21 @@ int at_pghi_realtime(const float* mag_hist, const float* mag, const float* prev_
   const size_t lds = sizeof(float) * (7 * (size_t)F + 1) + sizeof(HeapItem) * (4 * (size_t)F + 8);
   // ACIDS_PGHI_SERIAL=1 selects the single-lane kernels (debugging aid; identical results)
   static const bool serial_rt = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
-  if (lds <= 64 * 1024 && !serial_rt)
-    hipLaunchKernelGGL(pghi_hgi_rt_coop_kernel, dim3((unsigned)S), dim3(64), lds, s, p);
+  if (lds <= 64 * 1024 && !serial_rt) {
+    const size_t per_wave = (lds + 15) & ~(size_t)15;
+    // up to one stream per CU spreads best (256 streams: 3.5 ms alone on their CUs, 3.7 ms packed four to a CU);
+    // from four per CU on, a workgroup of four loads the CU's SIMDs evenly (1024 streams: 4.15 -> 3.88 ms)
+    int wpb = S >= 4 * 256 ? 4 : 1;
+    while (wpb > 1 && per_wave * wpb > 160 * 1024 - 1024) wpb >>= 1;
+    p.lds_floats_per_wave = (int)(per_wave / sizeof(float));
+    const size_t block_lds = per_wave * wpb;
+    if (block_lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)pghi_hgi_rt_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return AT_ELAUNCH;
+    }
+    hipLaunchKernelGGL(pghi_hgi_rt_coop_kernel, dim3((unsigned)((S + wpb - 1) / wpb)), dim3(64 * wpb), block_lds, s, p);
+  }
   else if (lds <= 64 * 1024)
     hipLaunchKernelGGL(pghi_hgi_rt_lds_kernel, dim3((unsigned)S), dim3(64), lds, s, p);
   else

@@ -125,7 +125,7 @@ if "pghi" in which:
     print("pghi B=%d  %.3f s  %.1f kframes/s  %.2f Mpops/s" % (nb, dt, nb * T / dt / 1e3, nb * T * 513 / dt / 1e6))
 if "rt" in which:
     import time
-    S, nfr = 256, int(os.environ.get("RT_FRAMES", "16"))
+    S, nfr = int(os.environ.get("RT_STREAMS", "256")), int(os.environ.get("RT_FRAMES", "16"))
     rt = A.RealtimeDGT(batch_size=[S]).to(dev)
     fr = torch.randn(S, nfr, 1024, device=dev) * 0.1
     Xr = rt(fr)
