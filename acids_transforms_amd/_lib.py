@@ -39,7 +39,7 @@ _SIGNATURES = {
     "at_resample_sinc": [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, c_i64, c_f, c_f],
     "at_sinebank_workspace_bytes": [c_i64, c_int, c_i64, c_int],
     "at_sinebank_offline": [c_f, c_i64, c_i64, c_int, c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_sz, c_f],
-    "at_sinebank_realtime": [c_f, c_i64, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f],
+    "at_sinebank_realtime": [c_f, c_i64, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f],
     "at_mel_project": [c_f, c_int, c_i64, c_i64, c_int, c_f, c_int, c_int, c_int, c_int, c_f, c_f, c_flt, c_f, c_i64,
                        c_i64, c_f],
     "at_mel_project_banded": [c_f, c_int, c_i64, c_i64, c_int, c_f, c_f, c_f, c_int, c_int, c_f, c_int, c_int, c_f, c_f,
@@ -114,7 +114,10 @@ def check(rc, what):
 
 
 def require_device(*tensors):
-    """Product path guard: HIP kernels only, never a silent CPU route."""
+    """Product path guard: HIP kernels only, never a silent CPU route; all operands on ONE device, and that
+    device must be the current one (ops.py enters it around every op: the kernels are launched on the current
+    stream of the current device and capi.hip picks its per-device tables with hipGetDevice())."""
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -122,8 +125,15 @@ def require_device(*tensors):
             raise AcidsHipError(
                 "acids_transforms_amd runs on MI355X only: got a %s tensor. Move inputs (and the module, "
                 "`.to('cuda')`) to the ROCm device; there is no CPU fallback." % t.device)
-    dev = next(t for t in tensors if t is not None).device
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise AcidsHipError("operands live on different devices (%s and %s): move them to one device"
+                                % (dev, t.device))
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx != torch.cuda.current_device():
+        raise AcidsHipError("operands are on cuda:%d but the current device is cuda:%d (call through "
+                            "acids_transforms_amd.ops, which enters the operands' device)" % (idx, torch.cuda.current_device()))
     if idx not in _inited:
         with torch.cuda.device(idx):
             check(lib().at_init(idx), "at_init")
@@ -137,3 +147,27 @@ def stream_ptr():
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def first_device_index(args, kwargs):
+    """Index of the first ROCm tensor among the arguments (None if there is none)."""
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.device.index
+    return None
+
+
+def device_scoped(fn):
+    """Run `fn` with the device of its first ROCm tensor argument as the current device, so that
+    `stream_ptr()` and the library's hipGetDevice() both see the operands' device (a module on cuda:1 used
+    while cuda:0 is current would otherwise launch on device 0 with device-1 pointers)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        idx = first_device_index(args, kwargs)
+        if idx is None or idx == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(idx):
+            return fn(*args, **kwargs)
+    return wrapped

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void sine_combine_kernel(const float* __restri
 // (argument in fp32 as the reference, reduced to revolutions in fp64, v_sin_f32).
 __global__ __launch_bounds__(256) void sinebank_rt_kernel(const float* __restrict__ x, const float* __restrict__ c,
                                                            const float* __restrict__ tau, const float* __restrict__ phi,
-                                                           long long S_, int T, int F, int N, float* __restrict__ out) {
+                                                           long long S_, int T, int F, int N,
+                                                           const float* __restrict__ window, float* __restrict__ out) {
   extern __shared__ float sh[];          // x row, c, phi row: 3 F floats
   float* xs = sh;
   float* cs = sh + F;
@@ -82,7 +83,9 @@ __global__ __launch_bounds__(256) void sinebank_rt_kernel(const float* __restric
     r -= rint(r);
     acc = acc + xs[k] * __builtin_amdgcn_sinf((float)r);
   }
-  out[st * N + n] = acc / (float)F;
+  acc = acc / (float)F;
+  if (window) acc = acc * window[n];     // invert(mode="sinebank") = frames * inv_window (stft.py:303-304)
+  out[st * N + n] = acc;
 }
 
 }  // namespace at_hip
@@ -129,13 +132,14 @@ int at_sinebank_offline(const float* x, int64_t B, int64_t T, int F, const float
 }
 
 int at_sinebank_realtime(const float* x, int64_t S_, int T, int F, int N, const float* c, const float* tau,
-                         const float* phi, float* out, void* stream) {
+                         const float* phi, const float* window_or_null, float* out, void* stream) {
   if (S_ < 0 || T <= 0 || F <= 0 || N <= 0) return AT_EINVAL;
   if (S_ == 0) return AT_OK;
   if (!x || !c || !tau || !phi || !out) return AT_EINVAL;
   if (S_ * T > 65535 || (size_t)F * 3 * sizeof(float) > 48 * 1024) return AT_EUNSUPPORTED;   // grid.y, LDS
   hipLaunchKernelGGL(sinebank_rt_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)(S_ * T)), dim3(256),
-                     3 * (size_t)F * sizeof(float), (hipStream_t)stream, x, c, tau, phi, (long long)S_, T, F, N, out);
+                     3 * (size_t)F * sizeof(float), (hipStream_t)stream, x, c, tau, phi, (long long)S_, T, F, N,
+                     window_or_null, out);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 

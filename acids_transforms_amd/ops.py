@@ -6,7 +6,7 @@ current torch stream.  No arithmetic happens in Python.
 """
 import torch
 
-from ._lib import check, lib, ptr, require_device, stream_ptr
+from ._lib import check, device_scoped, lib, ptr, require_device, stream_ptr
 
 
 def _f32c(t):
@@ -548,15 +548,16 @@ def sinebank_offline(x, c, t, phi, block_frame_offset, W3, max_abs, n_pass):
     return out
 
 
-def sinebank_realtime(x, c, tau, phi):
-    """x (S, T, F), tau (T, N), phi (S, F) -> (S, T, N) frames."""
-    require_device(x, c, tau, phi)
+def sinebank_realtime(x, c, tau, phi, window=None):
+    """x (S, T, F), tau (T, N), phi (S, F) -> (S, T, N) frames (times window (N,) when given)."""
+    require_device(x, c, tau, phi, window)
+    window = _f32c(window) if window is not None else None
     x, c, tau, phi = _f32c(x), _f32c(c), _f32c(tau), _f32c(phi)
     S, T, F = x.shape
     N = tau.shape[-1]
     out = torch.empty((S, T, N), dtype=torch.float32, device=x.device)
-    check(lib().at_sinebank_realtime(ptr(x), S, T, F, N, ptr(c), ptr(tau), ptr(phi), ptr(out), stream_ptr()),
-          "at_sinebank_realtime")
+    check(lib().at_sinebank_realtime(ptr(x), S, T, F, N, ptr(c), ptr(tau), ptr(phi), ptr(window), ptr(out),
+                                     stream_ptr()), "at_sinebank_realtime")
     return out
 
 
@@ -587,3 +588,11 @@ def stft_polar_forward(x, window, band, contrast=None, mag_offset=None, mag_scal
                                       contrast_code(contrast), ptr(mag_offset), ptr(mag_scale), eps, ptr(phase_offset),
                                       ptr(phase_scale), ptr(out), stream_ptr()), "at_stft_polar_forward")
     return out
+
+
+# every public op enters the device of its operands (see _lib.device_scoped)
+for _name, _fn in list(globals().items()):
+    if callable(_fn) and not _name.startswith("_") and getattr(_fn, "__module__", None) == __name__ \
+            and _name not in ("contrast_code",):
+        globals()[_name] = device_scoped(_fn)
+del _name, _fn

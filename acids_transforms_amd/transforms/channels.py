@@ -20,69 +20,91 @@ from .base import AudioTransform, InversionEnumType, NotInvertibleError
 __all__ = ["Mono", "Stereo", "MidSide", "Window", "Squeeze", "Unsqueeze", "Transpose"]
 
 
-class Mono(AudioTransform):
+# ---------------------------------------------------------------------------------------------------------
+# Two-channel stage.  Written from the behaviour table that tests/golden/g12_channels.npz pins (reference
+# transforms/raw.py:11-180), not from the reference's code:
+#
+#   transform        input channels   forward output (channel axis = -2)                 invert
+#   Mono(mix)        2                one channel, (L + R) / 2                          re-insert the axis; duplicate
+#   Mono(left|right) 2                one channel, L | R                                it when the MODULE's own
+#   Mono(any)        != 2             unchanged                                          inversion_mode == "stereo"
+#   Stereo           1 (or 1-D)       [x, x]                                             same rule; > 2 channels: keep
+#   Stereo           2                unchanged;  > 2: error                             the first two
+#   MidSide          1 (or 1-D)       [x, 0]                                             1 channel: [x, x]
+#   MidSide          2                [(L+R)/2 (/sqrt2 if pad_mid), (L-R)/2]             [M' + S, M' - S], M' = M*sqrt2
+#   all              --               normalize=True divides by the global max
+#
+# A 1-D signal counts as "one channel" whose channel axis is created in front (dim 0).
+# ---------------------------------------------------------------------------------------------------------
+def _n_channels(x: torch.Tensor) -> int:
+    return 1 if x.ndim == 1 else x.shape[-2]
+
+
+def _pair(first: torch.Tensor, second: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """Two signals -> one tensor with a 2-long channel axis; `like` says where that axis goes: a 1-D signal
+    gets it in front, a (..., 1, n) signal keeps its own."""
+    if like.ndim == 1:
+        return torch.stack([first, second], dim=0)
+    return torch.cat([first, second], dim=-2)
+
+
+def _peak_normalised(x: torch.Tensor, enabled: bool) -> torch.Tensor:
+    return x / x.max() if enabled else x
+
+
+class _ChannelStage(AudioTransform):
     scriptable = False
     invertible = True
     needs_scaling = False
 
+
+class Mono(_ChannelStage):
+    _PICK = {"left": 0, "right": 1}
+
     def __init__(self, mode: str = "mix", normalize: bool = False, squeeze: bool = True, inversion_mode="mono"):
         super().__init__()
-        self.mode = mode
-        self.squeeze = squeeze
-        self.normalize = normalize
-        self.inversion_mode = inversion_mode
+        self.mode, self.normalize, self.squeeze, self.inversion_mode = mode, normalize, squeeze, inversion_mode
 
     def __repr__(self):
         return "Mono(mode=%s, normalize=%s squeeze=%s, inversion_mode=%s)" % (self.mode, self.normalize, self.squeeze,
                                                                              self.inversion_mode)
 
-    def forward(self, x: Union[torch.Tensor, List[torch.Tensor]]):
-        if isinstance(x, list):
-            return [self(item) for item in x]
-        if x.shape[-2] == 2:
-            if self.mode == "mix":
-                x = (x.sum(-2) / 2).unsqueeze(-2)
-            elif self.mode == "right":
-                x = x[..., 1:2, :]
-            elif self.mode == "left":
-                x = x[..., 0:1, :]
-        if self.normalize:
-            x = x / x.max()
-        if self.squeeze:
-            x = x.squeeze(-2)
-        return x
-
-    def forward_with_time(self, x: torch.Tensor, time: torch.Tensor):
-        time = time[..., 0] if self.squeeze else time[..., 0].unsqueeze(-1)
-        return self(x), time
-
     def get_inversion_modes(self):
         return ["mono", "stereo"]
 
-    def invert(self, x, inversion_mode: InversionEnumType = None, tolerance: float = 0.0):
-        if self.squeeze:
-            x = x.unsqueeze(-2)
-        if x.shape[-2] == 1 and self.inversion_mode == "stereo":
-            x = torch.cat([x, x], dim=-2)
+    def _downmix(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[-2] != 2:
+            return x                                            # only a stereo pair is touched
+        if self.mode in self._PICK:
+            c = self._PICK[self.mode]
+            return x.narrow(-2, c, 1)
+        if self.mode == "mix":
+            return (x.sum(-2) / 2).unsqueeze(-2)
         return x
+
+    def forward(self, x: Union[torch.Tensor, List[torch.Tensor]]):
+        if isinstance(x, list):
+            return [self.forward(item) for item in x]
+        y = _peak_normalised(self._downmix(x), self.normalize)
+        return y.squeeze(-2) if self.squeeze else y
+
+    def forward_with_time(self, x: torch.Tensor, time: torch.Tensor):
+        t0 = time[..., 0]
+        return self(x), (t0 if self.squeeze else t0.unsqueeze(-1))
+
+    def invert(self, x, inversion_mode: InversionEnumType = None, tolerance: float = 0.0):
+        y = x.unsqueeze(-2) if self.squeeze else x
+        # the argument is ignored: the module's own setting decides (behaviour pinned by g12)
+        if self.inversion_mode == "stereo" and y.shape[-2] == 1:
+            y = torch.cat([y, y], dim=-2)
+        return y
 
     def test_inversion(self, x: torch.Tensor):
         y = self.forward(x)
         return {mode: self.invert(y, inversion_mode=mode) for mode in self.get_inversion_modes()}
 
 
-def _two_channels(x: torch.Tensor, second) -> torch.Tensor:
-    """1-D -> (2, n); (..., 1, n) -> (..., 2, n) with `second(x)` as the other channel."""
-    if x.ndim == 1:
-        return torch.stack([x, second(x)], dim=0)
-    return torch.cat([x, second(x)], dim=-2)
-
-
-class Stereo(AudioTransform):
-    scriptable = False
-    invertible = True
-    needs_scaling = False
-
+class Stereo(_ChannelStage):
     def __init__(self, normalize=False, sr=44100):
         super().__init__()
         self.normalize = normalize
@@ -90,28 +112,23 @@ class Stereo(AudioTransform):
     def __repr__(self):
         return "Stereo(normalize=%s)" % self.normalize
 
+    @staticmethod
+    def _widen(x: torch.Tensor, too_many) -> torch.Tensor:
+        n = _n_channels(x)
+        if n == 1:
+            return _pair(x, x, x)
+        return too_many(x) if n > 2 else x
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if x.ndim == 1 or x.shape[-2] == 1:
-            x = _two_channels(x, lambda t: t)
-        elif x.shape[-2] > 2:
+        def refuse(_):
             raise Exception("Stereo only works with 1/2 channels")
-        if self.normalize:
-            x = x / x.max()
-        return x
+        return _peak_normalised(self._widen(x, refuse), self.normalize)
 
     def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
-        if x.ndim == 1 or x.shape[-2] == 1:
-            return _two_channels(x, lambda t: t)
-        if x.shape[-2] > 2:
-            return x[..., :2, :]
-        return x
+        return self._widen(x, lambda t: t[..., :2, :])
 
 
-class MidSide(AudioTransform):
-    scriptable = False
-    invertible = True
-    needs_scaling = False
-
+class MidSide(_ChannelStage):
     def __init__(self, sr=44100, normalize=False, pad_mid=True):
         super().__init__(sr=sr)
         self.pad_mid = pad_mid
@@ -121,26 +138,23 @@ class MidSide(AudioTransform):
         return "MidSide(normalize=%s)" % self.normalize
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if x.ndim == 1 or x.shape[-2] == 1:
-            x = _two_channels(x, torch.zeros_like)          # mono: the side channel is silence
-        elif x.shape[-2] > 2:
+        n = _n_channels(x)
+        if n > 2:
             raise Exception("MidSide only works with 1 or 2 channels")
+        if n == 1:
+            y = _pair(x, torch.zeros_like(x), x)                # mono: it is all mid, the side channel is silence
         else:
-            left, right = x[..., 0, :], x[..., 1, :]
-            mid = (left + right) / 2
-            side = (left - right) / 2
+            left, right = x.unbind(-2)
+            mid, side = (left + right) / 2, (left - right) / 2
             if self.pad_mid:
                 mid = mid / math.sqrt(2)
-            x = torch.stack([mid, side], -2)
-        if self.normalize:
-            x = x / x.max()
-        return x
+            y = torch.stack([mid, side], -2)
+        return _peak_normalised(y, self.normalize)
 
     def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
-        if x.ndim == 1 or x.shape[-2] == 1:
-            return _two_channels(x, lambda t: t)
-        x = x[..., :2, :]
-        mid, side = x[..., 0, :], x[..., 1, :]
+        if _n_channels(x) == 1:
+            return _pair(x, x, x)
+        mid, side = x[..., 0, :], x[..., 1, :]                  # channels beyond the second are ignored
         if self.pad_mid:
             mid = mid * math.sqrt(2)
         return torch.stack([mid + side, mid - side], dim=-2)

@@ -177,7 +177,7 @@ class RealtimeDGT(DGT):
         elif inversion_mode == "random":
             phase = torch.pi * 2 * torch.rand_like(x)
         elif inversion_mode == "sinebank":
-            return self.get_sinebank_inversion(x)
+            return self.get_sinebank_inversion(x, windowed=True)
         else:
             raise ValueError("inversion mode %s not valid." % self.inversion_mode)
         n = self._n_fft
@@ -189,10 +189,11 @@ class RealtimeDGT(DGT):
             x, phase, self.inv_window[:n], n, self.hgi_mag_buffer)
         return frames
 
-    def get_sinebank_inversion(self, x_fft: torch.Tensor) -> torch.Tensor:
-        """Per-chunk oscillator bank (reference dgt.py:356-371): (..., n, F) -> (..., n, n_fft) frames."""
+    def get_sinebank_inversion(self, x_fft: torch.Tensor, windowed: bool = False) -> torch.Tensor:
+        """Per-chunk oscillator bank (reference dgt.py:356-371): (..., n, F) -> (..., n, n_fft) frames; windowed=True
+        multiplies by the dual window as `invert(mode="sinebank")` does (dgt.py:321-322)."""
         from .sinebank import sinebank_realtime
-        return sinebank_realtime(self, x_fft)
+        return sinebank_realtime(self, x_fft, self.inv_window[:self._n_fft] if windowed else None)
 
     def pghi(self, mag: torch.Tensor, tolerance=None, noise: torch.Tensor = None):
         """Streaming PGHI (reference dgt.py:338-354, 378-466) for (..., n, F) magnitudes using the

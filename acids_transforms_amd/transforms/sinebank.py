@@ -70,8 +70,9 @@ def sinebank_offline(x_fft: torch.Tensor, sr, n_fft: int, hop: int, random_phase
     return y.reshape(tuple(lead) + (L,))
 
 
-def sinebank_realtime(mod, x_fft: torch.Tensor) -> torch.Tensor:
-    """Per-chunk resynthesis with the module's running `time_index` and per-stream `random_phase`."""
+def sinebank_realtime(mod, x_fft: torch.Tensor, window: torch.Tensor = None) -> torch.Tensor:
+    """Per-chunk resynthesis with the module's running `time_index` and per-stream `random_phase`; `window`
+    (n_fft,) multiplies every frame (the realtime classes' invert(mode="sinebank"))."""
     T, F = x_fft.shape[-2], x_fft.shape[-1]
     batch_shape = tuple(x_fft.shape[:-2])
     n_fft, hop = mod._n_fft, mod._hop
@@ -90,7 +91,7 @@ def sinebank_realtime(mod, x_fft: torch.Tensor) -> torch.Tensor:
     for d in batch_shape:
         S *= d
     phi = mod.random_phase.to(dev).reshape(-1, F) if batch_shape else mod.random_phase.to(dev).reshape(1, F)
-    y = ops.sinebank_realtime(x_fft.reshape(S, T, F), c.to(dev), tau.to(dev), phi.expand(S, F).contiguous())
+    y = ops.sinebank_realtime(x_fft.reshape(S, T, F), c.to(dev), tau.to(dev), phi.expand(S, F).contiguous(), window)
     step = (T * hop + n_fft) / mod.sr
     mod.__dict__["_time_index_host"] = np.float32(now + np.float32(step))
     mod.time_index = mod.time_index + step

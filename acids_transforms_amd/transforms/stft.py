@@ -371,16 +371,17 @@ class RealtimeSTFT(STFT):
         elif inversion_mode == "random":
             phase = torch.pi * 2 * torch.rand_like(x)
         elif inversion_mode == "sinebank":
-            return self.get_sinebank_inversion(x)
+            return self.get_sinebank_inversion(x, windowed=True)
         else:
             raise ValueError("inversion mode %s not valid." % self.inversion_mode)
         return ops.irfft_frames(None, self.inv_window[:self._n_fft], self._n_fft, mag=x, phase=phase)
 
-    def get_sinebank_inversion(self, x_fft: torch.Tensor) -> torch.Tensor:
+    def get_sinebank_inversion(self, x_fft: torch.Tensor, windowed: bool = False) -> torch.Tensor:
         """Per-chunk oscillator bank with a running clock and per-stream phases (reference stft.py:276-291):
-        (..., n, F) magnitudes -> (..., n, n_fft) frames."""
+        (..., n, F) magnitudes -> (..., n, n_fft) frames.  windowed=True (what `invert(mode="sinebank")` returns,
+        stft.py:303-304): the frames times the synthesis window, in the same kernel."""
         from .sinebank import sinebank_realtime
-        return sinebank_realtime(self, x_fft)
+        return sinebank_realtime(self, x_fft, self.inv_window[:self._n_fft] if windowed else None)
 
     def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
         out = self(frame(x, self._n_fft, self._hop, -1))

@@ -6,16 +6,27 @@ already resident in HBM:
     X, feat = STFT.forward(x) + Magnitude(mel, n_mels=128).forward(X)   one fused kernel:
               X (B, 690, 513) complex64 and feat (B, 690, 128) float32 (log1p + unipolar normalise)
     y       = STFT.invert(X)                     (B, 176384)   float32
-(--unfused runs the two forward stages as separate kernels: STFT, then the MFMA projection)
-on BASELINE config[1]: batch = 1024 clips x 4 s @ 44.1 kHz mono per GPU, fp32.
-N > 1: one process per GPU (launched by torch.distributed.run), clips sharded,
-weak scaling, no data-path collective; `value` is the whole-job frames/s.
-Extra figures (all-gather of the features over RCCL, PGHI round trip, per-kernel
-roofline, CPU baseline) ride along in the same JSON line.
+(--unfused runs the two forward stages as separate kernels)
+on BASELINE configs[1]: batch = 1024 clips x 4 s @ 44.1 kHz mono per GPU, fp32.
+
+`--gpus N` with N > 1: when not already running under a launcher (no WORLD_SIZE in the
+environment) this process starts N ranks itself -- one child process per GPU, before anything
+touches the GPU -- relays rank 0's JSON line and exits with the children's status.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are the
+launcher's; a WORLD_SIZE that disagrees with --gpus is an error, never a silent N=1.
+Clips are sharded over ranks, weak scaling, no data-path collective; `value` is the whole-job
+frames/s.  `--pipeline config4` times BASELINE configs[3] instead (per GPU: 1024 clips -> fused
+STFT+mel128 -> MFCC(40); features reassembled with an RCCL all-gather) and reports its three
+figures: compute only, + all-gather fp32, + all-gather with a bf16 wire format.
+
+Side figures (per-kernel roofline, CPU baselines, PGHI round trip, streaming matrix, parity spot
+check of what the timed loop produced) ride along in the same JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,76 +42,169 @@ CLIP_LEN = 4 * SR                     # 176400 samples
 T_FRAMES = 1 + CLIP_LEN // HOP        # 690
 F_BINS = N_FFT // 2 + 1               # 513
 N_MELS = 128
+N_MFCC = 40
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s, ~6.3 achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3          # fp32-input MFMA spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA spec
 # algorithmic bytes per frame
 BYTES_STFT_FWD = HOP * 4 + F_BINS * 8            # 5128
 BYTES_ISTFT = F_BINS * 8 + HOP * 4               # 5128
 BYTES_MEL = F_BINS * 8 + N_MELS * 4              # 4616 (unfused: reads the complex spectrum)
+BYTES_FUSED_FEATURES_ONLY = HOP * 4 + N_MELS * 4  # 1536 (spectrum never stored)
 FLOPS_MEL = 2 * F_BINS * N_MELS                  # 131328 dense
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="clips per GPU")
+    ap.add_argument("--pipeline", choices=("step", "config4"), default="step",
+                    help="step: configs[1] fwd+mel+invert (the headline); config4: STFT+mel128+MFCC(40) + all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="STFT and Magnitude as two kernels (MFMA projection)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the all-gather / PGHI side measurements")
+    ap.add_argument("--unfused", action="store_true", help="STFT and Magnitude as two kernels")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
     ap.add_argument("--pghi-clips", type=int, default=1024, help="clips for the DGT+PGHI round-trip side measurement")
     ap.add_argument("--streams", type=int, default=256, help="concurrent streams for the RealtimeDGT side measurement")
+    ap.add_argument("--stream-steps", type=int, default=1000, help="steps per cell of the streaming matrix")
     return ap.parse_args()
 
 
-def cpu_baseline(sample_clips=96, reps=3):
-    """The oracle (CPU restatement, torch CPU ops) timed on this box's host cores on a bounded
+# ----------------------------------------------------------------------------------------------
+# rank launcher: the parent never touches the GPU and never re-execs
+# ----------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args) -> int:
+    n = args.gpus
+    rehearsal = os.environ.get("ACIDS_BENCH_REHEARSAL") == "1"
+    ndev = torch.cuda.device_count()          # counting devices does not initialise HIP
+    if not rehearsal and ndev < n:
+        print(json.dumps({"error": "--gpus %d asked for, %d ROCm device(s) visible: refusing to report a smaller "
+                                   "job under that name" % (n, ndev), "n_gpus_visible": ndev}))
+        return 3
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:               # one rank failed: the job failed; stop exactly the ranks we started
+                    q.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc if rc >= 0 else 1
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU baselines (the oracle timed on this box's host cores; rank 0, N = 1 only)
+# ----------------------------------------------------------------------------------------------
+def cpu_baseline(threads, sample_clips, budget_s=10.0):
+    """The oracle (CPU restatement: torch CPU stft + matmul + istft) on `threads` host threads, on a bounded
     sample of the same workload: STFT fwd + Magnitude(mel128) + ISTFT."""
     from oracle import oracle as O
-    threads = torch.get_num_threads()
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(sample_clips, CLIP_LEN, generator=g) * 0.1
-    w = O.hann_window(N_FFT)
-    fwd, _ = O.magnitude_banks(O.melscale_fbanks(F_BINS, 0.0, SR / 2, N_MELS, SR))
-    X = O.stft_forward(x[:4], w, N_FFT, HOP)
-    off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        g = torch.Generator().manual_seed(1234)
+        x = torch.randn(sample_clips, CLIP_LEN, generator=g) * 0.1
+        w = O.hann_window(N_FFT)
+        fwd, _ = O.magnitude_banks(O.melscale_fbanks(F_BINS, 0.0, SR / 2, N_MELS, SR))
+        X = O.stft_forward(x[:2], w, N_FFT, HOP)
+        off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
 
-    def step():
-        X = O.stft_forward(x, w, N_FFT, HOP)
-        O.magnitude_forward(X, fwd, "log1p", off, sc)
-        O.istft(X, w, N_FFT, HOP)
+        def step():
+            X = O.stft_forward(x, w, N_FFT, HOP)
+            O.magnitude_forward(X, fwd, "log1p", off, sc)
+            O.istft(X, w, N_FFT, HOP)
 
-    step()
-    t0 = time.perf_counter()
-    n = 0
-    while n < reps or (time.perf_counter() - t0 < 10.0 and n < 50):
         step()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 or (time.perf_counter() - t0 < budget_s and n < 50):
+            step()
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+    finally:
+        torch.set_num_threads(prev)
     return {"value": sample_clips * T_FRAMES / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d clips x 4 s (%d frames) per pass, %d passes, oracle = torch CPU stft+matmul+istft, %d threads"
-                      % (sample_clips, sample_clips * T_FRAMES, n, threads)}
+            "sample": "%d clips x 4 s (%d frames) per pass, %d passes, oracle = torch CPU stft+matmul+istft, %d threads "
+                      "(os.cpu_count() = %d)" % (sample_clips, sample_clips * T_FRAMES, n, threads, os.cpu_count())}
 
 
-def cpu_baseline_pghi(clips=2, frames=173):
-    """oracle/pghi_ref.c (exact-order C PGHI) on one host core, dense-noise magnitudes."""
+def synth_tonal(n_clips, length, seed=7, device="cpu"):
+    """SURVEY 8d C3's tonal set: 8 random-frequency exponentially decaying sinusoids per clip."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    f = 50.0 + 8000.0 * torch.rand(n_clips, 8, 1, generator=g)
+    a = 0.02 + 0.1 * torch.rand(n_clips, 8, 1, generator=g)
+    d = 0.3 + 3.0 * torch.rand(n_clips, 8, 1, generator=g)
+    ph = 6.2831853 * torch.rand(n_clips, 8, 1, generator=g)
+    f, a, d, ph = (t.to(device) for t in (f, a, d, ph))
+    t = torch.arange(length, device=device, dtype=torch.float32) / SR
+    out = torch.empty(n_clips, length, device=device)
+    for lo in range(0, n_clips, 64):
+        sl = slice(lo, lo + 64)
+        out[sl] = (a[sl] * torch.exp(-d[sl] * t) * torch.sin(6.2831853 * f[sl] * t + ph[sl])).sum(1)
+    return out
+
+
+def cpu_baseline_pghi(mag_noise, mag_tonal, threads):
+    """oracle/pghi_ref.c (exact-order C PGHI), one clip per host thread, on magnitudes computed by the device
+    DGT (the very inputs of the GPU figure)."""
     from oracle import oracle as O
-    import numpy as np
-    rng = np.random.RandomState(7)
-    mag = np.abs(rng.randn(clips, frames, F_BINS) + 1j * rng.randn(clips, frames, F_BINS)).astype(np.float32)
-    t0 = time.perf_counter()
-    O.pghi_offline_batch(mag, N_FFT, HOP)
-    dt = time.perf_counter() - t0
-    return {"value": clips * frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d clips x %d frames dense noise, exact-heap C PGHI, 1 thread" % (clips, frames)}
+    out = {}
+    for tag, mag in (("noise", mag_noise), ("tonal", mag_tonal)):
+        if mag is None:
+            continue
+        m = mag.numpy()
+        clips, frames = m.shape[0], m.shape[1]
+        res = {}
+        for th, nclips in ((1, min(clips, 4 if tag == "noise" else 32)), (threads, clips)):
+            t0 = time.perf_counter()
+            _, pops = O.pghi_offline_batch(m[:nclips], N_FFT, HOP, threads=th, want_pops=True)
+            dt = time.perf_counter() - t0
+            res["threads_%d" % th if th == 1 else "all_cores"] = {
+                "value": nclips * frames / dt, "unit": "frames/s", "cores": th, "kind": "port", "heap_pops_per_s": pops / dt,
+                "seconds": dt, "sample": "%d clips x %d frames, %s magnitudes, exact-heap C PGHI, %d thread(s), one clip per "
+                                         "thread at a time" % (nclips, frames, tag, th)}
+        out[tag] = res
+    return out
 
 
+# ----------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))          # parent: no GPU call before or after this point
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps({"error": "--gpus %d but WORLD_SIZE=%d: start bench.py as `python bench.py --gpus N` or under "
+                                       "torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world)}))
+        sys.exit(2)
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no ROCm device: bench.py measures the HIP path only"}))
         sys.exit(2)
@@ -109,12 +213,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        backend = dist.get_backend()
+        assert dist.get_world_size() == world
     red_dev = torch.device("cpu") if rehearsal else dev
     import acids_transforms_amd as A
 
@@ -127,12 +234,44 @@ def main():
     X = stft(x[:8])
     mag.scale_data(X)                                                  # one-off calibration, outside the timed region
     del X
+    mfcc = A.MFCC(sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS, n_mfcc=N_MFCC).to(dev)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
     fused = (not args.unfused) and mag.can_fuse_with(stft, x)
+    config4 = args.pipeline == "config4"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(seconds):
+        if world > 1:
+            tt = torch.tensor([seconds], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return seconds
+
+    def timed_region(fn, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    # -- the headline step ------------------------------------------------------------------------
     ktimes = {"stft_fwd": [], "mel": [], "istft": []}
+    last = {}
 
     def step(record=False):
+        e = None
         if record:
             e = [ev() for _ in range(4)]
             e[0].record()
@@ -151,12 +290,83 @@ def main():
         y = stft.invert(X)
         if record:
             e[3].record()
-            return X, feat, y, e
-        return X, feat, y, None
+        last["X"], last["feat"], last["y"] = X, feat, y
+        return e
 
-    def barrier():
+    # -- BASELINE configs[3]: per GPU 1024 clips -> fused STFT + mel128 (features only) -> MFCC(40) -----------
+    def config4_compute():
+        """log-mel (B, T, 128) from the fused kernel (the spectrum never goes to HBM) and its DCT-II, 40
+        coefficients, channel-major (B, 40, T) like the reference's MFCC layout."""
+        from acids_transforms_amd import ops as _ops
+        _, _, logmel = _ops.stft_mel_forward(x, mfcc.window, mfcc._band, "log", None, None, eps=1e-10, power=2,
+                                             want_spectrum=False)
+        coef = _ops.mel_forward_real(logmel, mfcc.dct, None, None, channel_major_T=logmel.shape[-2])
+        return logmel, coef
+
+    def config4_figures(steps, warmup):
+        from acids_transforms_amd.dist import all_gather_features
+        res = {}
+        t_compute = timed_region(config4_compute, steps, warmup)
+        res["compute_only"] = {"frames_per_s": world * frames_per_step * steps / t_compute,
+                               "ms_per_step": t_compute / steps * 1e3}
+        if world > 1 and not rehearsal:
+            comm = torch.cuda.Stream(device=dev)
+
+            def with_gather(wire_dtype, what):
+                pending = []
+
+                def fn():
+                    logmel, coef = config4_compute()
+                    done = torch.cuda.Event()
+                    done.record()
+                    for h in pending:                 # at most one gather in flight behind the next step's compute
+                        h.wait()
+                    pending.clear()
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(done)
+                        for t in ((logmel, coef) if what == "mel128+mfcc40" else (coef,)):
+                            t.record_stream(comm)
+                            wire = t if wire_dtype is None else t.to(wire_dtype)
+                            _, h = all_gather_features(wire, world * B, async_op=True)
+                            pending.append(h)
+
+                t = timed_region(fn, steps, warmup)
+                for h in pending:
+                    h.wait()
+                torch.cuda.synchronize()
+                return {"frames_per_s": world * frames_per_step * steps / t, "ms_per_step": t / steps * 1e3}
+
+            res["with_allgather_fp32"] = with_gather(None, "mel128+mfcc40")
+            res["with_allgather_bf16_wire"] = with_gather(torch.bfloat16, "mel128+mfcc40")
+            res["with_allgather_mfcc40_only_fp32"] = with_gather(None, "mfcc40")
+            res["wire_bytes_per_rank_fp32"] = B * T_FRAMES * (N_MELS + N_MFCC) * 4
+        res["note"] = ("per GPU: %d clips -> fused STFT+log-mel128 kernel (spectrum not stored) -> DCT-II 40; the gathers "
+                       "run on a side stream, overlapped with the next step's compute; timing includes them "
+                       "(barrier + synchronize on both sides)" % B)
+        return res
+
+    if config4:
+        c4 = config4_figures(args.steps, args.warmup)
+        key = "with_allgather_fp32" if "with_allgather_fp32" in c4 else "compute_only"
+        value = c4[key]["frames_per_s"]
+        ms_per_step = c4[key]["ms_per_step"]
+        result = {
+            "metric": "spectrogram frames/sec (STFT+mel128+MFCC40 fwd, features all-gathered), n_fft=1024 hop=256",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: batch=%d clips total (%d per GPU) x 4 s mono 44.1 kHz, STFT + mel128 + "
+                                   "MFCC(40), RCCL all-gather of the features; value = %s" % (world * B, B, key),
+                       "n_fft": N_FFT, "hop": HOP, "frames_per_clip": T_FRAMES, "clips_per_gpu": B,
+                       "sharding": "clips; all-gather only to reassemble outputs"},
+            "world_size_observed": dist.get_world_size() if world > 1 else 1, "backend": backend,
+            "config4": c4,
+        }
+        if rank == 0:
+            print(json.dumps(result))
         if world > 1:
-            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     for _ in range(args.warmup):
         step()
@@ -166,78 +376,19 @@ def main():
     t0 = time.perf_counter()
     evs = []
     for _ in range(args.steps):
-        out = step(record=True)
-        evs.append(out[3])
-    del out
+        evs.append(step(record=True))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     for e in evs:
         ktimes["stft_fwd"].append(e[0].elapsed_time(e[1]))
         ktimes["mel"].append(e[1].elapsed_time(e[2]))
         ktimes["istft"].append(e[2].elapsed_time(e[3]))
-    if world > 1:
-        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    del evs
     ms_per_step = elapsed / args.steps * 1e3
     value = world * frames_per_step * args.steps / elapsed
-
     avg = {k: sum(v) / len(v) for k, v in ktimes.items()}
-
-    def hbm_entry(name, bytes_per_frame):
-        a = frames_per_step * bytes_per_frame / (avg[name] * 1e-3) / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(avg[name], 4),
-                "algorithmic_bytes_per_frame": bytes_per_frame}
-
-    if fused:
-        # one kernel reads the audio and writes spectrum + features: 1024 + 4104 + 512 bytes per frame
-        kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD + 4 * N_MELS), hbm_entry("istft", BYTES_ISTFT)]
-        kernels[0]["kernel"] = "stft_fwd+mel (fused)"
-        # the stand-alone projection (what Magnitude.forward runs on its own), timed outside the step
-        Xs = stft(x)
-        for _ in range(2):
-            mag(Xs)
-        e0, e1 = ev(), ev()
-        e0.record()
-        for _ in range(5):
-            mag(Xs)
-        e1.record()
-        torch.cuda.synchronize()
-        avg["mel"] = e0.elapsed_time(e1) / 5
-        # the framing pass on its own (STFT.forward without the fused epilogue), also outside the step
-        e0, e1 = ev(), ev()
-        e0.record()
-        for _ in range(5):
-            Xs = stft(x)
-        e1.record()
-        torch.cuda.synchronize()
-        avg["stft_fwd_plain"] = e0.elapsed_time(e1) / 5
-        del Xs
-        kernels.append(hbm_entry("stft_fwd_plain", BYTES_STFT_FWD))
-        kernels[-1]["kernel"] = "stft_fwd (framing + FFT only, outside the step)"
-    else:
-        kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD), hbm_entry("istft", BYTES_ISTFT)]
-    kernels.append(hbm_entry("mel", BYTES_MEL))
-    kernels[-1]["kernel"] = "mel (stand-alone banded projection%s)" % (", outside the step" if fused else "")
-    kernels[-1]["note"] = ("HBM-bound banded walk (mel_banded.hip); the dense exact-fp32 MFMA contraction of mel.hip "
-                           "remains for banks that are not banded")
-    dominant = max(("stft_fwd", "istft"), key=lambda k: avg[k])
-    roof = dict(kernels[0] if dominant == "stft_fwd" else kernels[1])
-    roof.pop("algorithmic_bytes_per_frame")
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            key = dominant if (fused or dominant != "stft_fwd") else "stft_fwd_unfused"
-            traffic = json.load(open(pmc)).get(key)
-        except Exception:
-            traffic = None
-    roof["traffic"] = traffic
-    roof["kernel"] = {"stft_fwd": "stft1024_h256_fwd_kernel<false,%d>" % (1 if fused else 0),
-                      "istft": "istft1024_ola_kernel<0>"}[dominant]
 
     extras = {}
 
@@ -250,80 +401,167 @@ def main():
         except Exception as exc:
             extras[name + "_error"] = repr(exc)[:300]
 
-    def extra_allgather(wire_dtype=None):
-        # features reassembled on every rank with one RCCL all-gather on a side stream, overlapped with the next step
-        # (wire_dtype=torch.bfloat16: the shard is cast on the side stream first -- half the bytes over xGMI; the
-        # features computed and kept on the owning rank stay fp32)
-        from acids_transforms_amd.dist import all_gather_features
-        comm = torch.cuda.Stream(device=dev)
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        pending = None
-        for _ in range(args.steps):
-            _, feat, _, _ = step()
-            done = torch.cuda.Event()
-            done.record()
-            if pending is not None:
-                pending.wait()
-            with torch.cuda.stream(comm):
-                comm.wait_event(done)
-                feat.record_stream(comm)
-                wire = feat if wire_dtype is None else feat.to(wire_dtype)
-                _, pending = all_gather_features(wire, world * B, async_op=True)
-        if pending is not None:
-            pending.wait()
-        torch.cuda.synchronize()
-        barrier()
-        tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return world * frames_per_step * args.steps / float(tt.item())
+    # -- what did the timed loop produce?  clips {0, B/2-1, B-1} of the LAST timed step against the oracle --------
+    def parity_spot_check():
+        from oracle import oracle as O
+        ids = sorted({0, B // 2 - 1 if B > 1 else 0, B - 1})
+        xs = x[ids].cpu()
+        Xg, fg, yg = (last[k][ids].cpu() for k in ("X", "feat", "y"))
+        w = O.hann_window(N_FFT)
+        Xr = O.stft_forward(xs, w, N_FFT, HOP)
+        fwd, _ = O.magnitude_banks(O.melscale_fbanks(F_BINS, 0.0, SR / 2, N_MELS, SR))
+        off, sc = float(mag.norm.offset), float(mag.norm.scale)
+        fr = O.magnitude_forward(Xr, fwd, "log1p", off, sc)
+        yr = O.istft(Xr, w, N_FFT, HOP)
 
-    def extra_pghi():
-        # BASELINE config 3: DGT + PGHI invert round trip, dense noise (worst case: every bin above tolerance).
-        # One wave per clip, latency-bound: throughput grows with the number of clips in flight.
+        def rel(a, b):
+            return float((a - b).abs().max() / b.abs().max())
+
+        r = {"X": rel(torch.view_as_real(Xg), torch.view_as_real(Xr)), "feat": rel(fg, fr), "y": rel(yg, yr)}
+        return {"clips": ids, "max_rel": max(r.values()), "per_output": r, "tolerance": 1e-5,
+                "ok": bool(max(r.values()) < 1e-5),
+                "note": "outputs of the last timed step (rank 0) vs the oracle on CPU, max|d|/max|ref|"}
+
+    if rank == 0:
+        guarded("parity_spot_check", parity_spot_check)
+
+    def hbm_entry(name, bytes_per_frame, ms=None):
+        ms = avg[name] if ms is None else ms
+        a = frames_per_step * bytes_per_frame / (ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(ms, 4), "algorithmic_bytes_per_frame": bytes_per_frame}
+
+    def timed_ms(fn, n=10, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    if fused:
+        # one kernel reads the audio and writes spectrum + features: 1024 + 4104 + 512 bytes per frame
+        kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD + 4 * N_MELS), hbm_entry("istft", BYTES_ISTFT)]
+        kernels[0]["kernel"] = "stft_fwd+mel (fused)"
+        if rank == 0 and not args.no_extras:
+            Xs = stft(x)
+            avg["mel"] = timed_ms(lambda: mag(Xs))               # the stand-alone projection, outside the step
+            del Xs
+            avg["stft_fwd_plain"] = timed_ms(lambda: stft(x))    # framing + FFT only, outside the step
+            kernels.append(hbm_entry("stft_fwd_plain", BYTES_STFT_FWD))
+            kernels[-1]["kernel"] = "stft_fwd (framing + FFT only, outside the step)"
+            from acids_transforms_amd import ops as _ops
+            off_, sc_ = mag._affine()
+            avg["fwd_features_only"] = timed_ms(lambda: _ops.stft_mel_forward(
+                x, stft.window[:N_FFT], mag._banded(), "log1p", off_, sc_, mag._eps, want_spectrum=False))
+            kernels.append(hbm_entry("fwd_features_only", BYTES_FUSED_FEATURES_ONLY))
+            kernels[-1]["kernel"] = "stft_fwd+mel, features only (spectrum not stored; outside the step)"
+            kernels[-1]["note"] = ("literal configs[1] 'fwd': 1536 algorithmic B/frame; VALU/LDS-bound (FFT + band walk per "
+                                   "frame), not HBM-bound -- reported against its own HBM roofline for honesty")
+    else:
+        kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD), hbm_entry("istft", BYTES_ISTFT)]
+    if "mel" in avg and avg["mel"] > 0:
+        kernels.append(hbm_entry("mel", BYTES_MEL))
+        kernels[-1]["kernel"] = "mel (stand-alone banded projection%s)" % (", outside the step" if fused else "")
+    dominant = max(("stft_fwd", "istft"), key=lambda k: avg[k])
+    roof = dict(kernels[0] if dominant == "stft_fwd" else kernels[1])
+    roof.pop("algorithmic_bytes_per_frame")
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(dominant if (fused or dominant != "stft_fwd") else "stft_fwd_unfused")
+    roof["kernel"] = {"stft_fwd": "stft1024_h256_fwd_kernel (fused mel epilogue)" if fused else "stft1024_h256_fwd_kernel",
+                      "istft": "istft1024_ola_kernel"}[dominant]
+
+    # -- side measurements -----------------------------------------------------------------------------------
+    def extra_h2d_inclusive():
+        # the boundary handed host buffers: H2D of the audio + the step + D2H of features and audio (pinned memory)
+        xh = torch.empty(B, CLIP_LEN, pin_memory=True)
+        xh.copy_(x)
+        fh = torch.empty(B, T_FRAMES, N_MELS, pin_memory=True)
+        yh = torch.empty(B, HOP * (T_FRAMES - 1), pin_memory=True)
+
+        def one():
+            x.copy_(xh, non_blocking=True)
+            step()
+            fh.copy_(last["feat"], non_blocking=True)
+            yh.copy_(last["y"], non_blocking=True)
+            torch.cuda.synchronize()
+
+        one()
+        t1 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            one()
+        dt = (time.perf_counter() - t1) / n
+        return {"frames_per_s": frames_per_step / dt, "ms_per_step": dt * 1e3,
+                "bytes_h2d": xh.numel() * 4, "bytes_d2h": (fh.numel() + yh.numel()) * 4,
+                "note": "PCIe-inclusive: pinned host audio -> device, step, features + audio -> pinned host (the spectrum "
+                        "stays on the device); never `value`"}
+
+    def extra_pghi(collect):
+        # BASELINE configs[2]: DGT + PGHI invert round trip.  Dense noise is the worst case (every bin above the
+        # tolerance); the tonal set (8 decaying sinusoids per clip) is SURVEY 8d's second input.
         dgt = A.DGT(sr=SR, n_fft=N_FFT, hop_length=HOP).to(dev)
         pg = {}
-        for nb in sorted({min(args.pghi_clips, B), min(4 * args.pghi_clips, 4096)}):
-            xs = x if nb <= B else torch.randn(nb, CLIP_LEN, device=dev, generator=gen) * 0.1
-            m = dgt(xs[:nb]).abs()
-            yp = dgt.invert(m, inversion_mode="pghi")      # warm-up: first-touch of the (7 MB/clip) workspace
-            del yp
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            yp = dgt.invert(m, inversion_mode="pghi")
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            pg["clips_%d" % nb] = {"frames_per_s": nb * T_FRAMES / dt, "seconds": dt,
-                                   "heap_pops_per_s": float(nb) * T_FRAMES * F_BINS / dt}
-            del m, yp, xs
-        pg["input"] = "|DGT(randn*0.1)|: ~100% of bins above tolerance; PGHI + polar ISTFT"
+        sizes = sorted({min(args.pghi_clips, B), min(4 * args.pghi_clips, 4096)})
+        for tag in ("noise", "tonal"):
+            for nb in (sizes if tag == "noise" else sizes[:1]):
+                if tag == "noise":
+                    xs = x if nb <= B else torch.randn(nb, CLIP_LEN, device=dev, generator=gen) * 0.1
+                else:
+                    xs = synth_tonal(nb, CLIP_LEN, device=dev)
+                m = dgt(xs[:nb]).abs()
+                if nb == sizes[0]:
+                    collect[tag] = m[:256].cpu()              # the CPU baseline runs on the same magnitudes
+                yp = dgt.invert(m, inversion_mode="pghi")      # warm-up: first touch of the workspace
+                del yp
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                yp = dgt.invert(m, inversion_mode="pghi")
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                thr = m.amax(dim=(1, 2), keepdim=True) * float(dgt.tolerance)
+                pops = int((m >= thr).sum())
+                pg["%s_clips_%d" % (tag, nb)] = {"frames_per_s": nb * T_FRAMES / dt, "seconds": dt,
+                                                 "heap_pops_per_s": pops / dt, "bins_above_tolerance": pops / m.numel()}
+                del m, yp, xs
+        pg["input"] = ("noise: |DGT(randn*0.1)|, ~100% of bins above tolerance; tonal: 8 decaying sinusoids per clip; "
+                       "DGT.invert(mag, 'pghi') = gradients + heap integration + polar ISTFT")
         return pg
 
     def extra_stream():
-        # BASELINE config 5 (streaming): chunk -> OverlapAdd frames -> RealtimeDGT -> |X| -> RTPGHI -> irfft ->
-        # overlap-add, 1024-sample chunks (4 hops; the reference's streaming state needs chunks >= 768 samples),
-        # eager launches vs one hipGraph replay per chunk
+        # BASELINE configs[4]: 256 streams, RealtimeDGT fwd + bf16-MFMA mel + RTPGHI + inverse + overlap-add, one
+        # hipGraph replay per step; chunk sizes 256 (hop-sized step), 1024, 4096 samples
         from acids_transforms_amd.streaming import StreamingDGTSession
-        S, C = args.streams, 1024
-        chunk = torch.randn(S, C, device=dev, generator=gen) * 0.1
-        rtres = {"streams": S, "chunk_samples": C, "realtime_budget_ms": C / SR * 1e3,
-                 "mel": "%d log1p mel features per analysed frame inside the step (fp32 banded projection; a bf16 "
-                        "bank would break the 1e-5 parity bar)" % N_MELS}
-        for tag, use_graph in (("eager", False), ("hipgraph", True)):
-            sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=use_graph, mel_bands=N_MELS)
-            for _ in range(3):
-                sess.step(chunk)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            nst = 50
-            for _ in range(nst):
-                sess.step(chunk)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / nst
-            rtres["ms_per_chunk_" + tag] = dt * 1e3
-            rtres["frames_per_s_" + tag] = S * (C // HOP) / dt
-            del sess
+        S = args.streams
+        rtres = {"streams": S, "steps_per_cell": args.stream_steps, "cells": {}}
+        for C in (256, 1024, 4096):
+            chunk = torch.randn(S, C, device=dev, generator=gen) * 0.1
+            cell = {"realtime_budget_ms": C / SR * 1e3}
+            for tag, use_graph in (("eager", False), ("hipgraph", True)):
+                nst = args.stream_steps if use_graph else max(50, args.stream_steps // 10)
+                try:
+                    sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=use_graph, mel_bands=N_MELS,
+                                               mel_dtype="bf16")
+                except Exception as exc:
+                    cell["error_" + tag] = repr(exc)[:200]
+                    continue
+                for _ in range(5):
+                    sess.step(chunk)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nst):
+                    sess.step(chunk)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / nst
+                cell["ms_per_step_" + tag] = dt * 1e3
+                cell["steps_per_s_" + tag] = 1.0 / dt
+                cell["frames_per_s_" + tag] = S * (C // HOP) / dt
+                del sess
+            rtres["cells"]["chunk_%d" % C] = cell
+        rtres["mel"] = "bf16 MFMA projection (v_mfma_f32_32x32x16_bf16, fp32 accumulate), %d log1p mel features per frame" % N_MELS
         return rtres
 
     def extra_phase_repr():
@@ -332,101 +570,47 @@ def main():
         Xs = stft(x)
         res = {}
 
-        def timed(fn, n=5):
-            fn()
-            torch.cuda.synchronize()
-            e0, e1 = ev(), ev()
-            e0.record()
-            for _ in range(n):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / n
-
         def entry(ms, bytes_per_bin):
             a = frames_per_step * F_BINS * bytes_per_bin / (ms * 1e-3) / 1e9
             return {"ms": round(ms, 4), "achieved_GBps": round(a, 1), "frac_of_8TBps": round(a / HBM_PEAK_GBS, 4),
                     "algorithmic_bytes_per_bin": bytes_per_bin}
 
-        res["phase_angle"] = entry(timed(lambda: _ops.phase_scan(Xs, "angle")), 12)
-        res["if_forward"] = entry(timed(lambda: _ops.phase_scan(Xs, "forward")), 12)
+        res["phase_angle"] = entry(timed_ms(lambda: _ops.phase_scan(Xs, "angle"), 5, 1), 12)
+        res["if_forward"] = entry(timed_ms(lambda: _ops.phase_scan(Xs, "forward"), 5, 1), 12)
         inst = _ops.phase_scan(Xs, "forward")
-        res["if_invert_forward"] = entry(timed(lambda: _ops.phase_integrate(inst, "forward")), 8)
-        res["if_invert_central"] = entry(timed(lambda: _ops.phase_integrate(inst, "central")), 8)
+        res["if_invert_forward"] = entry(timed_ms(lambda: _ops.phase_integrate(inst, "forward"), 5, 1), 8)
+        res["if_invert_central"] = entry(timed_ms(lambda: _ops.phase_integrate(inst, "central"), 5, 1), 8)
         mg_ = Xs.abs()
-        res["polar_to_complex"] = entry(timed(lambda: _ops.polar_to_complex(mg_, inst)), 16)
-        res["note"] = "angle+unwrap+finite difference(+Normalize) fused, one thread per (clip, bin) column"
+        res["polar_to_complex"] = entry(timed_ms(lambda: _ops.polar_to_complex(mg_, inst), 5, 1), 16)
         return res
-
-    def extra_mfcc40():
-        # BASELINE config 4's per-GPU work: audio -> log-mel (fused STFT kernel) -> DCT-II, 40 coefficients
-        mf = A.MFCC(sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS, n_mfcc=40).to(dev)
-        for _ in range(2):
-            mf(x)
-        torch.cuda.synchronize()
-        e0, e1 = ev(), ev()
-        e0.record()
-        for _ in range(5):
-            mf(x)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
-        return {"ms": round(ms, 4), "frames_per_s": frames_per_step / (ms * 1e-3),
-                "note": "MFCC(n_mfcc=40) forward, 1024 clips: fused STFT+log-mel kernel + DCT projection (extension: the "
-                        "reference's MFCC class has no DCT)"}
 
     def extra_hbm_probe():
         # what this box's HBM gives a flat streaming kernel today (a measured ceiling next to the spec)
         n = 1 << 29                                   # 2 GiB of fp32
         a = torch.empty(n, device=dev)
         b = torch.empty(n, device=dev)
-
-        def timed(fn, reps=6):
-            fn()
-            fn()
-            torch.cuda.synchronize()
-            e0, e1 = ev(), ev()
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps * 1e-3
-
-        t_fill = timed(lambda: a.fill_(1.0))
-        t_copy = timed(lambda: b.copy_(a))
-        t_read = timed(lambda: a.sum())
+        t_fill = timed_ms(lambda: a.fill_(1.0), 6, 2) * 1e-3
+        t_copy = timed_ms(lambda: b.copy_(a), 6, 2) * 1e-3
+        t_read = timed_ms(lambda: a.sum(), 6, 2) * 1e-3
         return {"copy_GBps": round(2 * 4 * n / t_copy / 1e9, 1), "fill_GBps": round(4 * n / t_fill / 1e9, 1),
                 "read_sum_GBps": round(4 * n / t_read / 1e9, 1),
                 "note": "torch fill_/copy_/sum on 2 GiB fp32 buffers: the practical ceiling for the fractions above "
                         "(roofline.peak stays the 8 TB/s spec)"}
 
     def extra_other_hops():
-        # n_fft = 1024 at the other hops the sliding kernels cover (hop 128: 1379 frames per clip, 5.8 GB of spectrum)
         res = {}
         for hop in (128, 512):
             st = A.STFT(sr=SR, n_fft=N_FFT, hop_length=hop).to(dev)
             Xh = st(x)
-            st.invert(Xh)
-            torch.cuda.synchronize()
-            e = [ev() for _ in range(3)]
-            e[0].record()
-            for _ in range(3):
-                Xh = st(x)
-            e[1].record()
-            for _ in range(3):
-                st.invert(Xh)
-            e[2].record()
-            torch.cuda.synchronize()
-            f_ms, i_ms = e[0].elapsed_time(e[1]) / 3, e[1].elapsed_time(e[2]) / 3
+            f_ms = timed_ms(lambda: st(x), 3, 1)
+            i_ms = timed_ms(lambda: st.invert(Xh), 3, 1)
             frames = B * Xh.shape[-2]
-            res["hop_%d" % hop] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(f_ms, 4), "inverse_ms": round(i_ms, 4),
-                                   "frames_per_s_fwd_plus_inv": frames / ((f_ms + i_ms) * 1e-3)}
+            res["hop_%d" % hop] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(f_ms, 4),
+                                   "inverse_ms": round(i_ms, 4), "frames_per_s_fwd_plus_inv": frames / ((f_ms + i_ms) * 1e-3)}
             del Xh
         return res
 
     def extra_griffin_lim():
-        # STFT's default inversion mode (stft.py:37, 174-178): 30 iterations of {forward, phase update + inverse}
         m = stft(x).abs()
         stft.invert(m)
         torch.cuda.synchronize()
@@ -434,21 +618,19 @@ def main():
         stft.invert(m)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        return {"seconds": dt, "frames_per_s": frames_per_step / dt, "iterations": 30,
-                "note": "phase update fused into the inverse kernel's load stage; ~11.6 GB of HBM traffic per iteration"}
+        return {"seconds": dt, "frames_per_s": frames_per_step / dt, "iterations": 30}
 
+    pghi_inputs = {}
     if not args.no_extras:
         if rank == 0:
             guarded("hbm_probe", extra_hbm_probe)
+            guarded("h2d_inclusive", extra_h2d_inclusive)
             guarded("other_hops", extra_other_hops)
             guarded("griffin_lim_invert", extra_griffin_lim)
             guarded("phase_representations", extra_phase_repr)
-            guarded("mfcc40_forward", extra_mfcc40)
-        if world > 1 and not rehearsal:
-            guarded("with_feature_allgather_frames_per_s", extra_allgather)
-            guarded("with_feature_allgather_bf16_wire_frames_per_s", lambda: extra_allgather(torch.bfloat16))
+        guarded("config4", lambda: config4_figures(max(10, args.steps // 5), 3))     # all ranks: it holds collectives
         if rank == 0 and args.pghi_clips > 0:
-            guarded("pghi_invert", extra_pghi)
+            guarded("pghi_invert", lambda: extra_pghi(pghi_inputs))
         if rank == 0 and args.streams > 0:
             guarded("realtime_dgt_stream", extra_stream)
         barrier()
@@ -462,17 +644,44 @@ def main():
                                "unipolar)%s + ISTFT invert, fp32" % (B, " [one fused kernel]" if fused else ""),
                    "n_fft": N_FFT, "hop": HOP, "frames_per_clip": T_FRAMES, "clips_per_gpu": B,
                    "sharding": "clips, no data-path collective"},
+        "world_size_observed": dist.get_world_size() if world > 1 else 1, "backend": backend,
         "roofline": roof,
         "kernels": kernels,
     }
     result.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
-        result["cpu_baseline_pghi"] = cpu_baseline_pghi()
+        ncpu = os.cpu_count() or 1
+        result["cpu_baseline"] = cpu_baseline(ncpu, 96)
+        result["cpu_baseline_1thread"] = cpu_baseline(1, 8, budget_s=6.0)
+        if pghi_inputs:
+            result["cpu_baseline_pghi"] = cpu_baseline_pghi(pghi_inputs.get("noise"), pghi_inputs.get("tonal"), ncpu)
+            try:
+                gpu = result["pghi_invert"]
+                cpu = result["cpu_baseline_pghi"]
+                result["pghi_gpu_vs_all_cores"] = {
+                    t: gpu["%s_clips_%d" % (t, min(args.pghi_clips, B))]["frames_per_s"] / cpu[t]["all_cores"]["value"]
+                    for t in cpu}
+            except Exception:
+                pass
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from this round's own rocprofv3 --pmc passes
+    (tools/profile_gpu.sh writes profiles/rNN_pmc_traffic.json; the newest one is read)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            v = json.load(open(f)).get(key)
+            if v is not None:
+                return v, os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 if __name__ == "__main__":

@@ -278,9 +278,11 @@ int at_sinebank_offline(const float *x, int64_t B, int64_t T, int F, const float
                         float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* RealtimeSTFT/RealtimeDGT.get_sinebank_inversion (stft.py:276-291, dgt.py:356-371):
- * out[s, t, n] = (1/F) sum_k x[s, t, k] sin(c_k tau[t, n] + phi[s, k]);  x (S, T, F), tau (T, N), phi (S, F), out (S, T, N). */
+ * out[s, t, n] = (1/F) sum_k x[s, t, k] sin(c_k tau[t, n] + phi[s, k]);  x (S, T, F), tau (T, N), phi (S, F), out (S, T, N).
+ * window_or_null (N floats): the frames are multiplied by it -- what invert(mode="sinebank") hands to OverlapAdd
+ * (stft.py:303-304, dgt.py:321-322: get_sinebank_inversion(x) * inv_window). */
 int at_sinebank_realtime(const float *x, int64_t S, int T, int F, int N, const float *c, const float *tau,
-                         const float *phi, float *out, void *stream);
+                         const float *phi, const float *window_or_null, float *out, void *stream);
 
 /* ---- audio front end ------------------------------------------------------------------------------------- */
 /* torchaudio.transforms.Resample(orig, new) with default arguments, as utils/misc.py:31-33 uses it (algorithm

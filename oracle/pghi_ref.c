@@ -22,6 +22,8 @@
  * -ffp-contract=off so no FMA contraction changes a rounding.
  */
 #include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -398,4 +400,54 @@ long pghi_offline_batch_ref(const float *mag, int B, int T, int F, float gamma, 
         total += pghi_offline_ref(mag + (long)b * T * F, T, F, gamma, n_fft, hop, tol, eps,
                                   phase + (long)b * T * F, NULL, NULL, NULL);
     return total;
+}
+
+/* The same batch on `nthreads` host threads, one clip per thread at a time (clips are handed out by an
+ * atomic counter): the all-cores CPU baseline of bench.py (SURVEY.md 8d "C++ PGHI ... one thread per clip").
+ * The per-clip arithmetic is pghi_offline_ref itself, so the results are those of the serial driver. */
+typedef struct {
+    const float *mag;
+    float *phase;
+    int B, T, F, n_fft, hop;
+    float gamma, tol, eps;
+    atomic_int next;
+    atomic_long total;
+} mt_job_t;
+
+static void *mt_worker(void *arg)
+{
+    mt_job_t *j = (mt_job_t *)arg;
+    const long n = (long)j->T * j->F;
+    for (;;) {
+        int b = atomic_fetch_add(&j->next, 1);
+        if (b >= j->B)
+            break;
+        long np = pghi_offline_ref(j->mag + b * n, j->T, j->F, j->gamma, j->n_fft, j->hop, j->tol, j->eps,
+                                   j->phase + b * n, NULL, NULL, NULL);
+        atomic_fetch_add(&j->total, np);
+    }
+    return NULL;
+}
+
+long pghi_offline_batch_mt_ref(const float *mag, int B, int T, int F, float gamma, int n_fft, int hop,
+                               float tol, float eps, float *phase, int nthreads)
+{
+    if (nthreads < 1)
+        nthreads = 1;
+    if (nthreads > B)
+        nthreads = B > 0 ? B : 1;
+    mt_job_t job = {mag, phase, B, T, F, n_fft, hop, gamma, tol, eps, 0, 0};
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    int started = 0;
+    for (int i = 0; i < nthreads; i++)
+        if (pthread_create(&th[i], NULL, mt_worker, &job) == 0)
+            started++;
+        else
+            break;
+    if (started == 0)
+        mt_worker(&job);
+    for (int i = 0; i < started; i++)
+        pthread_join(th[i], NULL);
+    free(th);
+    return (long)atomic_load(&job.total);
 }

@@ -617,6 +617,14 @@ def g13():
         r = at.RealtimeSTFT(n_fft=128, hop_length=32)
         out["rt_unbatched_phase"] = r.random_phase.clone()
         out["rt_unbatched"] = torch.stack([r.get_sinebank_inversion(chunks[i, 0]) for i in range(2)])
+        # what the streaming chain actually consumes: invert(mode="sinebank") = oscillator-bank frames TIMES the
+        # synthesis window (stft.py:303-304, dgt.py:321-322)
+        for name, cls in (("rtstft_invert", at.RealtimeSTFT), ("rtdgt_invert", at.RealtimeDGT)):
+            r = cls(n_fft=128, hop_length=32)
+            ys = [r.invert(chunks[i], inversion_mode="sinebank") for i in range(2)]
+            out[name] = torch.stack(ys)
+            out[name + "_phase"] = r.random_phase
+            out[name + "_inv_window"] = r.inv_window[:128]
     finally:
         torch.rand = real_rand
     save("g13_sinebank", **out)

@@ -58,6 +58,69 @@ def test_shard_and_all_gather_gloo(n_clips):
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
+def _subgroup_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from acids_transforms_amd.dist import shard_bounds, sharded_apply
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        members = [1, 2]
+        g = dist.new_group(members)                       # every rank takes part in the creation
+        if rank in members:
+            torch.manual_seed(0)
+            x = torch.randn(5, 12)                         # ragged over two ranks: 3 + 2 clips
+            out = sharded_apply(lambda t: t * 2 + 1, x, gather=True, group=g)
+            assert torch.equal(out, x * 2 + 1)
+            lo, hi = shard_bounds(5, members.index(rank), 2)
+            assert torch.equal(sharded_apply(lambda t: t * 2 + 1, x, gather=False, group=g), x[lo:hi] * 2 + 1)
+        q.put((rank, "ok"))
+    except Exception as e:                                  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharding_follows_the_group_not_the_world():
+    """sharded_apply over a sub-group shards by the group's rank / size (it used the default group's)."""
+    world = 3
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok"), (2, "ok")], res
+
+
+def _run_bench(argv, env_extra):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-side launcher checks (the GPU box runs the real thing)")
+def test_bench_launcher_never_reports_a_smaller_job():
+    """`bench.py --gpus N` either runs N ranks or fails: fewer devices than ranks, a launcher WORLD_SIZE that
+    disagrees with --gpus, and a failing rank all end non-zero."""
+    import json
+    r = _run_bench(["--gpus", "2"], {})
+    assert r.returncode != 0 and "error" in json.loads(r.stdout.strip().splitlines()[-1])
+    r = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stdout
+    # rehearsal mode skips the device-count check, so both ranks really start (and fail: no device here);
+    # the parent must relay that failure
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"ACIDS_BENCH_REHEARSAL": "1"})
+    assert r.returncode != 0 and r.stdout.count("no ROCm device") == 2
+
+
 def test_shard_bounds_cover_everything():
     from acids_transforms_amd.dist import shard_bounds
     for n in [0, 1, 7, 8, 1024, 8191]:

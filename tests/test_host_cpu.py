@@ -123,10 +123,16 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower().replace("# oracle", ""), os.path.join(dirpath, f)
-    import acids_transforms_amd  # noqa: F401
+    # and at run time: importing the whole package (every transform, ops, streaming, dist) in a fresh interpreter
+    # must not pull in anything from oracle/
+    import subprocess
     import sys
-    assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules
-                   if "acids_transforms_amd" in getattr(sys.modules[m], "__name__", "") and False)
+    code = ("import sys; sys.path.insert(0, %r); import acids_transforms_amd, acids_transforms_amd.streaming, "
+            "acids_transforms_amd.dist, acids_transforms_amd.ops; "
+            "bad = [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]; "
+            "print('LOADED', bad); sys.exit(1 if bad else 0)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_melbank_properties():

@@ -302,3 +302,9 @@ def test_sinebank(golden):
     for i in range(2):
         y, now = O.sinebank_realtime(t("chunks")[i, 0], 44100, 128, 32, t("rt_unbatched_phase"), now)
         assert torch.allclose(y, t("rt_unbatched")[i], rtol=1e-5, atol=2e-6)
+    # invert(mode="sinebank") of the realtime classes = the frames times the synthesis window (stft.py:303-304)
+    for name in ("rtstft_invert", "rtdgt_invert"):
+        now = torch.tensor(0.)
+        for i in range(2):
+            y, now = O.sinebank_realtime(t("chunks")[i], 44100, 128, 32, t(name + "_phase"), now)
+            assert torch.allclose(y * t(name + "_inv_window"), t(name)[i], rtol=1e-5, atol=2e-6), (name, i)

@@ -52,8 +52,16 @@ def test_realtime_golden(golden, dev):
     r = A.RealtimeSTFT(n_fft=128, hop_length=32).to(dev)
     r.random_phase = T_(g["rt_unbatched_phase"]).to(dev)
     for i in range(2):
-        y = r.invert(chunks[i, 0], inversion_mode="sinebank")
+        y = r.get_sinebank_inversion(chunks[i, 0])
         assert rel_max(cpu(y).numpy(), g["rt_unbatched"][i]) < TOL
+    # invert(mode="sinebank") hands OverlapAdd the frames TIMES the synthesis window (stft.py:303-304, dgt.py:321-322)
+    for name, cls in (("rtstft_invert", A.RealtimeSTFT), ("rtdgt_invert", A.RealtimeDGT)):
+        ri = cls(n_fft=128, hop_length=32).to(dev)
+        ri.random_phase = T_(g[name + "_phase"]).to(dev)
+        assert np.allclose(cpu(ri.inv_window[:128]).numpy(), g[name + "_inv_window"], rtol=1e-6, atol=1e-7)
+        for i in range(2):
+            y = ri.invert(chunks[i], inversion_mode="sinebank")
+            assert rel_max(cpu(y).numpy(), g[name][i]) < TOL, (name, i)
     r.reset()
     y0 = r.get_sinebank_inversion(chunks[0, 0])
     assert rel_max(cpu(y0).numpy(), g["rt_unbatched"][0]) < TOL          # the clock restarts
