@@ -44,6 +44,9 @@ _SIGNATURES = {
                        c_i64, c_f],
     "at_mel_project_banded": [c_f, c_int, c_i64, c_i64, c_int, c_f, c_f, c_f, c_int, c_int, c_f, c_int, c_int, c_f, c_f,
                               c_flt, c_f, c_i64, c_i64, c_f, c_i64, c_f, c_f, c_f, c_f],
+    "at_mel_bf16_bank_bytes": [c_int, c_int],
+    "at_mel_bf16_pack_bank": [c_f, c_int, c_int, c_int, c_f, c_f],
+    "at_mel_project_bf16": [c_f, c_int, c_i64, c_i64, c_int, c_f, c_int, c_int, c_f, c_f, c_flt, c_f, c_i64, c_f],
     "at_project_small": [c_f, c_i64, c_int, c_f, c_int, c_f, c_f, c_f, c_i64, c_f],
     "at_mag_pointwise": [c_f, c_int, c_i64, c_int, c_int, c_f, c_f, c_flt, c_f, c_f],
     "at_stats_workspace_bytes": [],
@@ -61,13 +64,14 @@ _SIGNATURES = {
     "at_scale_complex": [c_f, c_f, c_i64, c_f, c_f],
     "at_oadd_forward": [c_f, c_f, c_int, c_i64, c_int, c_i64, c_f, c_f, c_f],
     "at_oadd_invert": [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
+    "at_oadd_push": [c_f, c_int, c_i64, c_int, c_i64, c_f, c_f],
     "at_mulaw_encode": [c_f, c_i64, c_int, c_f, c_f],
     "at_mulaw_decode": [c_f, c_f, c_i64, c_int, c_f, c_f],
     "at_onehot": [c_f, c_i64, c_int, c_i64, c_f, c_f],
     "at_argmax_last": [c_f, c_f, c_i64, c_int, c_f, c_f],
 }
 _RESTYPES = {"at_error_string": ctypes.c_char_p, "at_istft_workspace_bytes": c_sz, "at_stats_workspace_bytes": c_sz,
-             "at_pghi_offline_workspace_bytes": c_sz, "at_pghi_rt_workspace_bytes": c_sz,
+             "at_pghi_offline_workspace_bytes": c_sz, "at_mel_bf16_bank_bytes": c_sz, "at_pghi_rt_workspace_bytes": c_sz,
              "at_sinebank_workspace_bytes": c_sz}
 
 

@@ -122,25 +122,48 @@ __global__ void oadd_forward_kernel(const float* __restrict__ x, const float* __
   }
 }
 
-__global__ void oadd_invert_kernel(const float* __restrict__ frames, const float* __restrict__ tail_in, int S, int n,
-                                   int n_fft, int hop, int keep, const float* gain, float* __restrict__ out,
-                                   float* __restrict__ tail_out) {
+// One workgroup per stream.  The carried tail is staged in LDS before anything is written, so tail_out may be the
+// very buffer tail_in points to (the streaming session updates its state in place, no copy afterwards).
+__global__ __launch_bounds__(256) void oadd_invert_kernel(const float* frames, const float* tail_in, int S, int n,
+                                                          int n_fft, int hop, int keep, const float* gain, float* out,
+                                                          float* tail_out) {
+  extern __shared__ float tail_lds[];
   const long long rec_len = (long long)(n - 1) * hop + n_fft;
   const long long out_len = rec_len - keep;
-  const long long total = (long long)S * rec_len;
   const float g = *gain;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long s = i / rec_len, p = i - s * rec_len;
-    float acc = (tail_in && p < keep) ? tail_in[s * keep + p] : 0.f;
-    long long t_hi = p / hop;
-    if (t_hi > n - 1) t_hi = n - 1;
-    long long t_lo = (p >= n_fft) ? (p - n_fft + hop) / hop : 0;
-    for (long long t = t_lo; t <= t_hi; ++t) {  // ascending frame order, like the reference's += loop
-      const long long o = p - t * hop;
-      if (o >= 0 && o < n_fft) acc += frames[(s * n + t) * n_fft + o];
+  for (long long s = blockIdx.x; s < S; s += gridDim.x) {
+    for (int j = threadIdx.x; j < keep; j += blockDim.x) tail_lds[j] = tail_in ? tail_in[s * keep + j] : 0.f;
+    __syncthreads();
+    for (long long p = threadIdx.x; p < rec_len; p += blockDim.x) {
+      float acc = p < keep ? tail_lds[p] : 0.f;
+      long long t_hi = p / hop;
+      if (t_hi > n - 1) t_hi = n - 1;
+      long long t_lo = (p >= n_fft) ? (p - n_fft + hop) / hop : 0;
+      for (long long t = t_lo; t <= t_hi; ++t) {  // ascending frame order, like the reference's += loop
+        const long long o = p - t * hop;
+        if (o >= 0 && o < n_fft) acc += frames[(s * n + t) * n_fft + o];
+      }
+      if (p < out_len) out[s * out_len + p] = acc / g;
+      else tail_out[s * keep + (p - out_len)] = acc;
     }
-    if (p < out_len) out[s * out_len + p] = acc / g;
-    else tail_out[s * keep + (p - out_len)] = acc;
+    __syncthreads();
+  }
+}
+
+// Streaming input state kept IN PLACE: buf (S, buf_len) holds [history | previous chunk | pad].  One step moves the last
+// `keep` samples of [history | previous chunk] to the front and writes the new chunk behind them -- what
+// OverlapAdd.forward does with its input_buffer (oadd.py:33-42, 69-74), for any chunk length C >= 1 (a hop-sized chunk
+// included: the regions overlap then, hence the LDS staging).  One workgroup per stream.
+__global__ __launch_bounds__(256) void oadd_push_kernel(const float* __restrict__ x, int S, long long C, int keep,
+                                                        long long buf_len, float* buf) {
+  extern __shared__ float win_lds[];
+  for (long long s = blockIdx.x; s < S; s += gridDim.x) {
+    float* b = buf + s * buf_len;
+    for (int j = threadIdx.x; j < keep; j += blockDim.x) win_lds[j] = b[C + j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < keep; j += blockDim.x) b[j] = win_lds[j];
+    for (long long j = threadIdx.x; j < C; j += blockDim.x) b[keep + j] = x[s * C + j];
+    __syncthreads();
   }
 }
 
@@ -248,7 +271,8 @@ int at_affine(const float* x, int64_t n, const float* offset, const float* scale
 int at_oadd_forward(const float* x, const float* hist_in_or_null, int S, int64_t C, int keep, int64_t buf_len,
                     float* buf, float* hist_out, void* stream) {
   if (S < 0 || C <= 0 || keep < 0 || buf_len < keep + C) return AT_EINVAL;
-  if (C < keep) return AT_EINVAL;  // the reference's history slice silently shortens here (oadd.py:41)
+  // C < keep (e.g. one hop per step) is an extension: the reference's history slice silently shortens there and its
+  // next call fails (oadd.py:41); here hist_out is always the last `keep` samples of [history | chunk]
   if (S == 0) return AT_OK;
   if (!x || !buf || !hist_out) return AT_EINVAL;
   hipLaunchKernelGGL(oadd_forward_kernel, dim3(grid_for((long long)S * buf_len, 256)), dim3(256), 0, (hipStream_t)stream, x,
@@ -262,9 +286,19 @@ int at_oadd_invert(const float* frames, const float* tail_in_or_null, int S, int
   if ((long long)(n - 1) * hop + n_fft < keep) return AT_EINVAL;
   if (S == 0) return AT_OK;
   if (!frames || !gain || !out || !tail_out) return AT_EINVAL;
-  const long long rec_len = (long long)(n - 1) * hop + n_fft;
-  hipLaunchKernelGGL(oadd_invert_kernel, dim3(grid_for((long long)S * rec_len, 256)), dim3(256), 0, (hipStream_t)stream,
-                     frames, tail_in_or_null, S, n, n_fft, hop, keep, gain, out, tail_out);
+  if ((size_t)keep * sizeof(float) > 64 * 1024) return AT_EUNSUPPORTED;
+  hipLaunchKernelGGL(oadd_invert_kernel, dim3(S < 65535 ? S : 65535), dim3(256), (size_t)keep * sizeof(float),
+                     (hipStream_t)stream, frames, tail_in_or_null, S, n, n_fft, hop, keep, gain, out, tail_out);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+int at_oadd_push(const float* x, int S, int64_t C, int keep, int64_t buf_len, float* buf, void* stream) {
+  if (S < 0 || C <= 0 || keep < 0 || buf_len < keep + C) return AT_EINVAL;
+  if (S == 0) return AT_OK;
+  if (!x || !buf) return AT_EINVAL;
+  if ((size_t)keep * sizeof(float) > 64 * 1024) return AT_EUNSUPPORTED;
+  hipLaunchKernelGGL(oadd_push_kernel, dim3(S < 65535 ? S : 65535), dim3(256), (size_t)keep * sizeof(float),
+                     (hipStream_t)stream, x, S, (long long)C, keep, (long long)buf_len, buf);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 

@@ -244,6 +244,7 @@ static int set_lds(const void* fn, size_t bytes) {
 int launch_rfft_generic(const float* x, long long B, long long L, long long clip_stride, long long T, int n_fft,
                         int hop, int center, const float* window, float2* out, float* phase, hipStream_t stream) {
   if (B * T == 0) return 0;
+  if (B * T >= (1LL << 31)) return -2;       // one workgroup per frame: the grid is 32-bit (AT_EUNSUPPORTED)
   const int use_tw = n_fft <= 4096;
   GenFwdParams p = {x, window, out, phase, B, L, clip_stride, T, n_fft, hop, center, use_tw};
   size_t lds = sizeof(float2) * (size_t)(n_fft + (use_tw ? 3 * n_fft / 8 + 1 : 0));  // 2 * M (+ 3 M / 4 + 1 twiddles)
@@ -256,6 +257,7 @@ int launch_rfft_generic(const float* x, long long B, long long L, long long clip
 int launch_irfft_generic(const float2* X, const float* mag, const float* phase, long long nframes, int n_fft,
                          const float* window, float* frames, hipStream_t stream) {
   if (nframes == 0) return 0;
+  if (nframes >= (1LL << 31)) return -2;     // AT_EUNSUPPORTED rather than a wrapped grid
   const int use_tw = n_fft <= 4096;
   GenInvParams p = {X, mag, phase, window, frames, n_fft, use_tw};
   size_t lds = sizeof(float2) * (size_t)(n_fft + 2 + (use_tw ? 3 * n_fft / 8 + 1 : 0));   // a, b (+ twiddles)

@@ -172,7 +172,7 @@ def polar_forward(x, band, contrast=None, mag_offset=None, mag_scale=None, eps=1
 
 
 def mel_forward(x, bank, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1, channel_major_T=0,
-                band=None):
+                band=None, out=None):
     """normalise(contrast(|x|^power @ bank)); x: (..., K) complex64/float32, bank: (K, N).
     channel_major_T = T > 0 stores (..., N, T) for x of shape (..., T, K) (MelSpectrogram layout).
     band: utils.banded.BandedBank of `bank` (eligible) -> the HBM-bound banded walk instead of the dense MFMA
@@ -183,18 +183,42 @@ def mel_forward(x, bank, contrast=None, offset=None, scale=None, eps=1.1920929e-
     assert x.shape[-1] == K, "last dim of the input (%d) must match the bank (%d)" % (x.shape[-1], K)
     if band is not None and band.eligible and K <= 640:
         shape = (x.shape[:-2] + (N, channel_major_T)) if channel_major_T else (x.shape[:-1] + (N,))
-        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        out = _out_buffer(out, shape, x.device)
         return _project_banded(x, _a_kind(x, power), band, contrast, False, offset, scale, eps, out, N, channel_major_T)
     bank2 = bank.reshape(K, N)
     bank2 = bank2 if bank2.is_contiguous() else bank2.contiguous()
     rows = x.numel() // K
     if channel_major_T:
-        out = torch.empty(x.shape[:-2] + (N, channel_major_T), dtype=torch.float32, device=x.device)
+        out = _out_buffer(out, x.shape[:-2] + (N, channel_major_T), x.device)
     else:
-        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        out = _out_buffer(out, x.shape[:-1] + (N,), x.device)
     check(lib().at_mel_project(ptr(x), _a_kind(x, power), rows, K, K, ptr(bank2), N, N, contrast_code(contrast), 0,
                                ptr(offset), ptr(scale), eps, ptr(out), N, channel_major_T, stream_ptr()),
           "at_mel_project")
+    return out
+
+
+def mel_bf16_pack_bank(bank):
+    """(K, N) fp32 bank -> the bf16 operand image of at_mel_project_bf16 (a uint8 tensor, opaque)."""
+    require_device(bank)
+    K, N = bank.shape[-2], bank.shape[-1]
+    b2 = _f32c(bank.reshape(K, N))
+    img = torch.empty(lib().at_mel_bf16_bank_bytes(K, N), dtype=torch.uint8, device=bank.device)
+    check(lib().at_mel_bf16_pack_bank(ptr(b2), K, N, N, ptr(img), stream_ptr()), "at_mel_bf16_pack_bank")
+    return img
+
+
+def mel_forward_bf16(x, bank_image, K, N, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1,
+                     out=None):
+    """normalise(contrast(bf16(|x|^power) @ bf16(bank))), fp32 accumulation on the bf16 matrix cores.
+    x: (..., K) complex64 / float32; bank_image: mel_bf16_pack_bank(bank) of a (K, N) bank."""
+    require_device(x, bank_image)
+    x = _prep_in(x)
+    assert x.shape[-1] == K, "last dim of the input (%d) must match the bank (%d)" % (x.shape[-1], K)
+    out = _out_buffer(out, x.shape[:-1] + (N,), x.device)
+    check(lib().at_mel_project_bf16(ptr(x), _a_kind(x, power), x.numel() // K, K, K, ptr(bank_image), N,
+                                    contrast_code(contrast), ptr(offset), ptr(scale), eps, ptr(out), N, stream_ptr()),
+          "at_mel_project_bf16")
     return out
 
 
@@ -217,12 +241,21 @@ def mel_inverse(y, inv_bank, contrast=None, offset=None, scale=None, eps=1.19209
     return out
 
 
-def mag_pointwise(x, contrast=None, offset=None, scale=None, eps=1.1920929e-07, inverse=False):
+def _out_buffer(out, shape, device):
+    """Caller-supplied result buffer (persistent outputs of a captured streaming step) or a fresh one."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != device:
+        raise ValueError("out= must be a contiguous float32 tensor of shape %s on %s" % (tuple(shape), device))
+    return out
+
+
+def mag_pointwise(x, contrast=None, offset=None, scale=None, eps=1.1920929e-07, inverse=False, out=None):
     """mel=False chains: normalise(contrast(|x|)) or invert_contrast(x*scale+offset)."""
     require_device(x)
     x = _prep_in(x)
     kind = 2 if inverse else _a_kind(x)
-    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    out = _out_buffer(out, x.shape, x.device)
     check(lib().at_mag_pointwise(ptr(x), kind, x.numel(), contrast_code(contrast), int(inverse), ptr(offset),
                                  ptr(scale), eps, ptr(out), stream_ptr()), "at_mag_pointwise")
     return out
@@ -315,6 +348,18 @@ def pghi_realtime(mag_hist, mag, prev_phase, noise, gamma, n_fft, hop, tol, eps=
     return (phase, tg, fg) if debug else phase
 
 
+def rt_update_buffers_(mag, phase, mag_hist, prev_phase):
+    """RealtimeDGT.update_buffers (dgt.py:330-336) IN PLACE on the state tensors mag_hist (S, 2, F) and
+    prev_phase (S, F), for x = mag * exp(i * phase) with mag / phase (S, n, F)."""
+    require_device(mag, phase, mag_hist, prev_phase)
+    mag, phase = _f32c(mag), _f32c(phase)
+    S, n, F = mag.shape
+    assert mag_hist.is_contiguous() and prev_phase.is_contiguous() and mag_hist.dtype == torch.float32
+    assert tuple(mag_hist.shape) == (S, 2, F) and tuple(prev_phase.shape) == (S, F)
+    check(lib().at_rt_update_buffers(ptr(mag), ptr(phase), S, n, F, ptr(mag_hist), ptr(mag_hist), ptr(prev_phase),
+                                     stream_ptr()), "at_rt_update_buffers")
+
+
 def rt_polar_irfft_update(mag, phase, inv_window, n_fft, mag_hist):
     """x = mag*exp(i*phase): windowed irfft frames (..., n, n_fft) plus the refreshed PGHI
     history buffers (|x[-2:]|, angle(x[-1]))."""
@@ -340,8 +385,9 @@ def oadd_forward(x2d, hist, keep, n_fft, hop):
     require_device(x2d)
     x2d = _f32c(x2d)
     S, C = x2d.shape
-    if C < keep:
-        raise ValueError("OverlapAdd needs chunks of at least %d samples (got %d)" % (keep, C))
+    if C < keep and C % hop:
+        # reference granularity is keep samples (oadd.py:41); shorter chunks are an extension for whole hops only
+        raise ValueError("OverlapAdd needs chunks of at least %d samples, or a whole number of hops (got %d)" % (keep, C))
     total = keep + C
     nw = n_frames(total, n_fft, hop)
     buf_len = max(total, nw * hop + n_fft)
@@ -352,14 +398,29 @@ def oadd_forward(x2d, hist, keep, n_fft, hop):
     return buf, new_hist, nw
 
 
-def oadd_invert(frames3d, tail, n_fft, hop, keep, gain):
-    """frames (S, n, n_fft), tail (S, keep) or None -> (out (S, (n-1)*hop+n_fft-keep), new_tail (S, keep))."""
+def oadd_push_(buf, x2d, keep):
+    """Streaming input state in place: buf (S, >= keep + C) = [history | chunk | pad] <- [last keep samples of
+    (history | old chunk) | x2d | pad]."""
+    require_device(buf, x2d)
+    x2d = _f32c(x2d)
+    S, C = x2d.shape
+    assert buf.is_contiguous() and buf.dtype == torch.float32 and buf.shape[0] == S and buf.shape[1] >= keep + C
+    check(lib().at_oadd_push(ptr(x2d), S, C, keep, buf.shape[1], ptr(buf), stream_ptr()), "at_oadd_push")
+
+
+def oadd_invert(frames3d, tail, n_fft, hop, keep, gain, out=None, in_place=False):
+    """frames (S, n, n_fft), tail (S, keep) or None -> (out (S, (n-1)*hop+n_fft-keep), new_tail (S, keep)).
+    in_place=True: `tail` itself is updated (and returned)."""
     require_device(frames3d, gain)
     frames3d = _f32c(frames3d)
     S, n, _ = frames3d.shape
     out_len = (n - 1) * hop + n_fft - keep
-    out = torch.empty((S, out_len), dtype=torch.float32, device=frames3d.device)
-    new_tail = torch.empty((S, keep), dtype=torch.float32, device=frames3d.device)
+    out = _out_buffer(out, (S, out_len), frames3d.device)
+    if in_place:
+        assert tail is not None and tail.is_contiguous() and tuple(tail.shape) == (S, keep)
+        new_tail = tail
+    else:
+        new_tail = torch.empty((S, keep), dtype=torch.float32, device=frames3d.device)
     check(lib().at_oadd_invert(ptr(frames3d), ptr(tail), S, n, n_fft, hop, keep, ptr(gain), ptr(out), ptr(new_tail),
                                stream_ptr()), "at_oadd_invert")
     return out, new_tail

@@ -1,9 +1,13 @@
 """OverlapAdd: streaming framer and overlap-add with carried state
 (reference transforms/oadd.py:6-104).  `forward` writes [history | chunk] once
 and returns the frames as a zero-copy strided view (as the reference's `frame`
-does); `invert` is one gather-form overlap-add kernel.  Chunks must hold at
-least (n_fft/hop - 1)*hop samples -- the granularity at which the reference's
-own streaming state stays well formed (oadd.py:41)."""
+does); `invert` is one gather-form overlap-add kernel.  The reference's own
+streaming state is only well formed for chunks of at least (n_fft/hop - 1)*hop
+samples (oadd.py:41: shorter ones raise on the following call).  Extension:
+shorter chunks are accepted when they are a whole number of hops (down to one
+hop per call, BASELINE config 5's per-hop step); the frame sequence and the
+overlap-added output stream are then, sample for sample, those of any other
+chunking of the same input (the sums are taken in the same order)."""
 from typing import Union
 
 import torch

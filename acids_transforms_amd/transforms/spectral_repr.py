@@ -39,8 +39,13 @@ class Magnitude(AudioTransform):
 
     def __init__(self, sr: int = 44100, mode: Union[str, None] = "unipolar", contrast: ContrastModeType = "log1p",
                  mel: bool = True, n_fft: int = 1024, dtype: torch.dtype = None, eps: float = None,
-                 keep_nyquist: bool = True, n_mels: int = None):
+                 keep_nyquist: bool = True, n_mels: int = None, bank_dtype: str = "fp32"):
         super().__init__(sr=sr)
+        if bank_dtype not in ("fp32", "bf16"):
+            raise ValueError("bank_dtype must be 'fp32' or 'bf16', got %r" % (bank_dtype,))
+        # "bf16" (added option; BASELINE config 5): forward projection as a dense bf16 MFMA GEMM with fp32
+        # accumulation -- ~4e-3 relative to the fp32 chain, so never the default; invert stays fp32
+        self.bank_dtype = bank_dtype
         self.norm = _Identity() if (mode is None or mode == "none") else Normalize(mode)
         self.contrast_mode = contrast
         self.mel = mel
@@ -95,10 +100,20 @@ class Magnitude(AudioTransform):
             cache[name] = (key, BandedBank(bank))
         return cache[name][1] if cache[name][1].eligible else None
 
+    def _bf16_image(self):
+        """bf16 operand image of `mel_bank` for the MFMA projection; rebuilt when the buffer changes."""
+        bank = self.mel_bank
+        key = (bank.data_ptr(), bank._version, bank.device)
+        hit = self.__dict__.get("_bf16_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.mel_bf16_pack_bank(bank))
+            self.__dict__["_bf16_cache"] = hit
+        return hit[1]
+
     def _banded(self):
         """Banded form of `mel_bank` for the fused forward kernel (None when the bank is not banded
         enough, or when this module's options rule the fusion out)."""
-        if not self.mel or not self.keep_nyquist:
+        if not self.mel or not self.keep_nyquist or self.bank_dtype != "fp32":
             return None
         return self._band_of("mel_bank")
 
@@ -143,7 +158,10 @@ class Magnitude(AudioTransform):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._follow(x)
         off, sc = self._affine()
-        if self.mel:
+        if self.mel and self.bank_dtype == "bf16":
+            K, N = self.mel_bank.shape[-2], self.mel_bank.shape[-1]
+            mag = ops.mel_forward_bf16(x, self._bf16_image(), K, N, self.contrast_mode, off, sc, self._eps)
+        elif self.mel:
             mag = ops.mel_forward(x, self.mel_bank, self.contrast_mode, off, sc, self._eps,
                                   band=self._band_of("mel_bank"))
         else:

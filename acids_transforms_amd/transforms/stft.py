@@ -233,7 +233,31 @@ class STFT(AudioTransform):
             x_inv = self._istft(x)
         return x_inv.reshape(batch_shape + x_inv.shape[-1:])
 
+    def _check_nola(self, T: int) -> None:
+        """torch.istft's window-envelope check (the reference calls torch.istft, stft.py:120-128): the overlap-added
+        squared window over the T frames, n_fft/2 trimmed at both ends, must stay above 1e-11 -- otherwise the
+        division by the envelope yields inf/NaN samples.  Host-side, cached per (window, T)."""
+        n, h = self._n_fft, self._hop
+        w = self.inv_window
+        key = (w.data_ptr(), w._version, n, h, T)
+        cache = self.__dict__.setdefault("_nola_cache", {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            w2 = (w[:n].detach().cpu().double()) ** 2
+            expected = n + h * (T - 1)
+            env = torch.zeros(expected, dtype=torch.float64)
+            idx = (torch.arange(T).unsqueeze(1) * h + torch.arange(n).unsqueeze(0)).reshape(-1)
+            env.index_add_(0, idx, w2.repeat(T))
+            core = env[n // 2:n // 2 + h * (T - 1)]
+            cache[key] = float(core.abs().min()) if core.numel() else 1.0
+        if cache[key] < 1e-11:
+            raise RuntimeError("istft(n_fft=%d, hop_length=%d): window overlap add min: %g -- the window envelope "
+                               "vanishes somewhere (NOLA violated), as torch.istft would report" % (n, h, cache[key]))
+
     def _istft(self, X=None, mag=None, phase=None):
+        src = X if X is not None else mag
+        self._check_nola(int(src.shape[-2]))
         env = self._env16 if self._env16.numel() else None
         return ops.istft(X, self.inv_window[:self._n_fft], self._n_fft, self._hop, env16=env, mag=mag, phase=phase)
 

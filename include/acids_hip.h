@@ -128,6 +128,20 @@ int at_mel_project(const void *A, int a_kind, int64_t rows, int64_t lda, int K, 
                    int contrast, int inverse, const float *offset, const float *scale, float eps, float *out,
                    int64_t ld_out, int64_t T_transposed, void *stream);
 
+/* The forward projection as a dense bf16 MFMA GEMM with fp32 accumulation (v_mfma_f32_32x32x16_bf16): BASELINE
+ * config 5's "bf16 MFMA mel".  Same chain as at_mel_project with inverse = 0 -- normalise(contrast(A' @ bank)),
+ * spectral_repr.py:215-226 -- but A' (|x|, |x|^2 or the real input) and the bank are rounded to bf16 (nearest even)
+ * before the products; sums are fp32.  ~4e-3 relative to the fp32 chain: opt-in only (Magnitude(bank_dtype="bf16")),
+ * never the default.  The bank is passed as the packed operand image written by at_mel_bf16_pack_bank
+ * (at_mel_bf16_bank_bytes(K, N) bytes, 16-byte aligned): [ceil32(N)][ceil16(K)] bf16, k contiguous, zero padded.
+ * out: rows x N fp32, row stride ld_out.  K up to 4096 (one 32-column tile of the bank must fit in LDS), else
+ * AT_EUNSUPPORTED. */
+size_t at_mel_bf16_bank_bytes(int K, int N);
+int at_mel_bf16_pack_bank(const float *bank, int K, int ldb, int N, void *bank_bf16, void *stream);
+int at_mel_project_bf16(const void *A, int a_kind, int64_t rows, int64_t lda, int K, const void *bank_bf16, int N,
+                        int contrast, const float *offset, const float *scale, float eps, float *out, int64_t ld_out,
+                        void *stream);
+
 /* Magnitude with mel=False: the same chains without the projection (n elements). */
 int at_mag_pointwise(const void *A, int a_kind, int64_t n, int contrast, int inverse, const float *offset,
                      const float *scale, float eps, float *out, void *stream);
@@ -175,7 +189,8 @@ int at_pghi_realtime(const float *mag_hist, const float *mag, const float *prev_
                      void *stream);
 
 /* RealtimeDGT.update_buffers (dgt.py:330-336) for x = mag*exp(i*phase):
- * hist_out = |x[-2:]| (or [hist_in[1], |x[-1]|] when n == 1), phase_out = angle(x[-1]). */
+ * hist_out = |x[-2:]| (or [hist_in[1], |x[-1]|] when n == 1), phase_out = angle(x[-1]).  hist_out may alias hist_in
+ * (every bin reads its history before it writes it). */
 int at_rt_update_buffers(const float *mag, const float *phase, int S, int n, int F, const float *hist_in,
                          float *hist_out, float *phase_out, void *stream);
 
@@ -201,13 +216,20 @@ int at_scale_complex(const float *mag, const float *z_complex, int64_t n, float 
 /* ---- K6/K7: OverlapAdd streaming framer / overlap-add ---------------------- */
 /* OverlapAdd.forward (oadd.py:69-74, 33-42): buf (S, buf_len) = [history | chunk | 0...],
  * hist_out = last `keep` samples of [history | chunk].  The caller takes the
- * (S, n, n_fft) frames as a strided view of buf (utils/misc.py:148-165).  C >= keep. */
+ * (S, n, n_fft) frames as a strided view of buf (utils/misc.py:148-165).  C < keep (down to one hop per step) is
+ * an extension: the reference's own state breaks there (oadd.py:41); the frame sequence is that of any other
+ * chunking of the same sample stream. */
 int at_oadd_forward(const float *x, const float *hist_in_or_null, int S, int64_t C, int keep, int64_t buf_len,
                     float *buf, float *hist_out, void *stream);
 /* OverlapAdd.invert (oadd.py:90-104): frames (S, n, n_fft) + carried tail (S, keep)
- * -> out (S, (n-1)*hop + n_fft - keep) / gain, tail_out (S, keep) undivided. */
+ * -> out (S, (n-1)*hop + n_fft - keep) / gain, tail_out (S, keep) undivided.  tail_out may alias tail_in_or_null
+ * (state updated in place); n = 1 emits one hop.  keep <= 16384. */
 int at_oadd_invert(const float *frames, const float *tail_in_or_null, int S, int n, int n_fft, int hop, int keep,
                    const float *gain, float *out, float *tail_out, void *stream);
+/* The input side of the same state kept in place (streaming sessions, hipGraph replay): buf (S, buf_len) holds
+ * [history(keep) | chunk(C) | pad]; one call moves the last `keep` samples of [history | chunk] to the front and
+ * writes the new chunk x (S, C) behind them (oadd.py:33-42, 69-74).  Any C >= 1; buf_len >= keep + C. */
+int at_oadd_push(const float *x, int S, int64_t C, int keep, int64_t buf_len, float *buf, void *stream);
 
 /* ---- K16: integer transforms -------------------------------------------------- */
 /* torchaudio MuLawEncoding / MuLawDecoding as used by MuLaw (raw.py:282-283, 316):

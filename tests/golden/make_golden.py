@@ -653,10 +653,52 @@ def g14():
     save("g14_other_hops", **out)
 
 
+# --------------------------------------------------------------------------
+# G15: the per-hop streaming step = the reference's RealtimeDGT driven ONE frame per call (its own n = 1 path:
+# update_buffers' single-frame branch, dgt.py:333-335).  The reference's OverlapAdd cannot take one-hop chunks
+# (oadd.py:41), and framing / overlap-add do not depend on the chunking, so the frames come from a chunked
+# OverlapAdd.forward and the synthesised frames go through a chunked OverlapAdd.invert.
+# --------------------------------------------------------------------------
+def g15():
+    out = {}
+    for tag, n, h, nsteps, seed in [("a", 1024, 256, 12, 150), ("b", 64, 16, 12, 151)]:
+        torch.manual_seed(seed)
+        S = 2
+        keep = n - h
+        L = nsteps * h
+        x = torch.stack([sig_noise((L,), seed) * 0.3, sig_tonal(L) + 1e-3 * sig_noise((L,), seed + 100)])
+        oa, oi = at.OverlapAdd(n, h), at.OverlapAdd(n, h)
+        rt = at.RealtimeDGT(n_fft=n, hop_length=h, batch_size=[S])
+        chunk = 4 * h if 4 * h >= keep else keep
+        assert L % chunk == 0
+        frames = torch.cat([oa(x[:, c:c + chunk]) for c in range(0, L, chunk)], -2)       # (S, nsteps, n)
+        assert frames.shape[-2] == nsteps
+        out[tag + "_x"] = x
+        out[tag + "_params"] = np.array([n, h, nsteps, chunk])
+        out[tag + "_frames"] = frames
+        ys = []
+        for j in range(nsteps):
+            X = rt(frames[:, j:j + 1])
+            mag = X.abs()
+            noise = []
+            with rt_patches(noise):
+                yf = rt.invert(mag, inversion_mode="pghi")                                 # n = 1
+            ys.append(yf)
+            out["%s_mag_%d" % (tag, j)] = mag
+            out["%s_noise_%d" % (tag, j)] = torch.stack(noise)
+            out["%s_yframes_%d" % (tag, j)] = yf
+            out["%s_magbuf_%d" % (tag, j)] = rt.hgi_mag_buffer
+            out["%s_phasebuf_%d" % (tag, j)] = rt.hgi_phase_buffer
+        yframes = torch.cat(ys, -2)
+        per = chunk // h
+        out[tag + "_y"] = torch.cat([oi.invert(yframes[:, c:c + per]) for c in range(0, nsteps, per)], -1)
+    save("g15_rtpghi_per_hop", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14", "g15"]
     table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13,
-             "g14": g14}
+             "g14": g14, "g15": g15}
     for w in which:
         print("==", w)
         table[w]()

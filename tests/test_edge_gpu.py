@@ -114,3 +114,24 @@ def test_pghi_tiny_and_ragged_batches(dev):
                                         debug=True)
     k = len(r["order"])
     assert int(npops[0]) == k and np.array_equal(cpu(order[0][:k]), r["order"][:, 0] * 65 + r["order"][:, 1])
+
+
+def test_operands_on_mixed_devices_are_rejected_and_other_device_works(dev):
+    """every op runs with its operands' device current (stream + per-device tables), and operands on
+    different devices are refused.  The second half needs two devices."""
+    from acids_transforms_amd import AcidsHipError, ops
+    import acids_transforms_amd as A
+    x = torch.randn(2, 4096, device=dev)
+    with pytest.raises(AcidsHipError):
+        ops.stft_forward(x, torch.hann_window(1024), 1024, 256)          # CPU window: no silent CPU route
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one device: the cross-device half needs two")
+    d1 = torch.device("cuda:1")
+    with pytest.raises(AcidsHipError):
+        ops.stft_forward(x, torch.hann_window(1024, device=d1), 1024, 256)
+    s0, s1 = A.STFT().to(dev), A.STFT().to(d1)
+    assert torch.cuda.current_device() == 0
+    X1 = s1(x.to(d1))                                                     # current device is cuda:0
+    assert X1.device == d1 and torch.cuda.current_device() == 0
+    assert torch.equal(X1.cpu(), s0(x).cpu())
+    assert torch.equal(s1.invert(X1).cpu(), s0.invert(s0(x)).cpu())

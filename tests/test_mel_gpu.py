@@ -387,3 +387,64 @@ def test_magnitude_at_other_fft_sizes(dev, n_fft):
         y = mg(X.to(dev))
         assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL
         assert rel_max(cpu(mg.invert(y)), O.magnitude_invert(yr, inv, "log1p", off, sc).numpy()) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------------------
+# bf16 MFMA projection (BASELINE config 5; opt-in `Magnitude(bank_dtype="bf16")`)
+# ----------------------------------------------------------------------------------------------------------
+BF16_TOL = 4e-3          # vs the fp32 chain: both operands keep 8 significant bits (SURVEY hard part 5)
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("rows,K,N", [(1000, 513, 128), (1, 513, 128), (129, 513, 40), (300, 513, 513), (77, 257, 64),
+                                      (260, 129, 128), (33, 1025, 96), (5, 33, 7)])
+def test_bf16_projection_exact_operands(dev, rows, K, N):
+    """Operands that ARE bf16 numbers: the products are exact in fp32, only the summation order differs from a
+    CPU matmul -- the MFMA contraction itself is checked at the fp32 bar (1e-5), every tile shape / edge."""
+    from acids_transforms_amd import ops
+    g = torch.Generator().manual_seed(rows * 7 + K + N)
+    a = _bf16(torch.rand(rows, K, generator=g) * 3.0 - 0.5)
+    bank = _bf16(torch.rand(K, N, generator=g) * (torch.rand(K, N, generator=g) < 0.3))      # asymmetric, sparse-ish
+    img = ops.mel_bf16_pack_bank(bank.to(dev))
+    y = ops.mel_forward_bf16(a.to(dev), img, K, N)
+    want = a.double() @ bank.double()
+    assert y.shape == (rows, N)
+    assert rel_max(cpu(y), want.numpy()) < TOL
+    # |.| of real input, contrast and normalisation in the epilogue
+    off, sc = torch.tensor(0.25, device=dev), torch.tensor(1.75, device=dev)
+    y2 = ops.mel_forward_bf16((-a).to(dev), img, K, N, "log1p", off, sc)
+    want2 = (torch.log1p(a.abs().double() @ bank.double()) - 0.25) / 1.75
+    assert rel_max(cpu(y2), want2.numpy()) < TOL
+
+
+@pytest.mark.parametrize("contrast", ["log1p", "none", "log"])
+def test_bf16_magnitude_vs_oracle(dev, contrast):
+    """Magnitude(bank_dtype="bf16") on a complex spectrum: (a) against the oracle chain evaluated on bf16-rounded
+    operands -- tight (a magnitude that lands within an fp32 ulp of a bf16 rounding boundary may round the other
+    way: 1e-3); (b) against the fp32 oracle at the stated bf16 tolerance 4e-3."""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(6, 9000, generator=g) * 0.1
+    Xr = O.stft_forward(x, O.hann_window(1024), 1024, 256)
+    fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100))
+    off, sc = O.magnitude_scale_stats(Xr, contrast, "unipolar")
+    m = A.Magnitude(n_mels=128, mode="unipolar", contrast=contrast, bank_dtype="bf16").to(dev)
+    Xd = Xr.to(dev)
+    m.scale_data(Xd)
+    y = m(Xd)
+    assert y.shape == (6, Xr.shape[1], 128) and y.dtype == torch.float32
+    want_fp32 = O.magnitude_forward(Xr, fwd, contrast, off, sc)
+    want_bf16 = O.affine(O.contrast(_bf16(Xr.abs()) @ _bf16(fwd[0] if fwd.dim() == 3 else fwd), contrast), off, sc)
+    assert rel_max(cpu(y), want_bf16.numpy()) < 1e-3
+    assert rel_max(cpu(y), want_fp32.numpy()) < BF16_TOL
+    # and it IS the bf16 path: the fp32 module differs from it by more than fp32 noise
+    m32 = A.Magnitude(n_mels=128, mode="unipolar", contrast=contrast).to(dev)
+    m32.scale_data(Xd)
+    assert rel_max(cpu(m32(Xd)), want_fp32.numpy()) < TOL
+    assert rel_max(cpu(y), cpu(m32(Xd))) > 1e-5
+    # invert stays on the fp32 chain
+    assert rel_max(cpu(m.invert(m32(Xd))), cpu(m32.invert(m32(Xd)))) == 0.0
+    with pytest.raises(ValueError):
+        A.Magnitude(bank_dtype="fp8")

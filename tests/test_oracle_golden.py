@@ -118,6 +118,33 @@ def test_rtpghi_kernel(golden, tag):
     assert np.all(np.abs(r["phase"] - ref) <= tol_arr)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_rtpghi_per_hop(golden, tag):
+    """The reference's RealtimeDGT called one frame at a time (G15): the oracle at n = 1, state carried by the
+    oracle's own update_buffers restatement but re-seated on the reference's after every hop."""
+    g = golden("g15_rtpghi_per_hop")
+    n, h, nsteps, chunk = [int(v) for v in g[tag + "_params"]]
+    F = n // 2 + 1
+    magbuf, phasebuf = np.zeros((2, 2, F), np.float32), np.zeros((2, F), np.float32)
+    dw = O.dual_window(O.gauss_window(n), n, h)
+    fa = O.OverlapAddState(n, h)
+    x = T(g[tag + "_x"])
+    frames = torch.cat([fa.forward(x[:, c:c + chunk]) for c in range(0, x.shape[-1], chunk)], -2)
+    assert np.array_equal(frames.numpy(), g[tag + "_frames"])
+    for j in range(nsteps):
+        X = O.rt_forward(frames[:, j:j + 1], O.gauss_window(n))
+        assert rel_max(X.abs().numpy(), g["%s_mag_%d" % (tag, j)]) < 3e-6
+        mag = g["%s_mag_%d" % (tag, j)]
+        r = O.pghi_realtime(magbuf, mag, phasebuf, g["%s_noise_%d" % (tag, j)], n, h)
+        yf = O.rt_invert(O.polar_to_complex(T(mag), T(r["phase"])), dw).numpy()
+        ref = g["%s_yframes_%d" % (tag, j)]
+        snr = 10 * np.log10((ref ** 2).sum() / max(((yf - ref) ** 2).sum(), 1e-30))
+        assert snr > 40.0, (j, snr)
+        _, mh, pp = O.rt_update_buffers(mag, r["phase"], magbuf)
+        assert np.allclose(np.asarray(mh), g["%s_magbuf_%d" % (tag, j)], rtol=1e-5, atol=1e-6)
+        magbuf, phasebuf = g["%s_magbuf_%d" % (tag, j)], g["%s_phasebuf_%d" % (tag, j)]
+
+
 @pytest.mark.parametrize("key", ["1024_256_4096", "1024_256_1024", "64_16_128"])
 def test_overlap_add_stream(golden, key):
     g = golden("g6_overlap_add")

@@ -56,7 +56,7 @@ def test_overlap_add_vs_oracle_multidim_and_errors(dev):
         yr = ri.invert(frr * 0.5)
         assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < 1e-6
     with pytest.raises(ValueError):
-        A.OverlapAdd(1024, 256).to(dev)(torch.zeros(2, 256, device=dev))    # hop-sized chunks are not a valid stream
+        A.OverlapAdd(1024, 256).to(dev)(torch.zeros(2, 300, device=dev))    # short AND not a whole number of hops
 
 
 def test_mulaw_onehot_bit_exact(dev):
@@ -124,3 +124,141 @@ def test_graph_captured_streaming_session_matches_modules(dev):
         assert rel_max(cpu(sess.mel_out), cpu(mel(rt(fr)))) < 1e-5, c
     # the resynthesis follows the input (PGHI keeps the magnitudes, re-estimates the phase)
     assert bool(torch.isfinite(y).all()) and float(y.abs().max()) > 1e-3
+
+
+# ----------------------------------------------------------------------------------------------------------
+# hop-sized steps (BASELINE config 5; SURVEY hard part 9: "same output stream as the chunked run")
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("key,step", [("1024_256_4096", 256), ("1024_256_1024", 256), ("1024_256_4096", 512),
+                                      ("64_16_128", 16)])
+def test_overlap_add_per_hop_equals_chunked_golden(golden, dev, key, step):
+    """The reference's chunked OverlapAdd goldens (G6), reproduced by feeding the same samples one hop (or two) per
+    call: frames bit exact (data movement), overlap-added audio bit-identical to our own chunked run (same
+    summation order) and within 1e-5 of the reference's."""
+    g = golden("g6_overlap_add")
+    n, h, chunk = [int(v) for v in key.split("_")]
+    x = T_(g["x_" + key]).to(dev)
+    fa, fi = A.OverlapAdd(n, h).to(dev), A.OverlapAdd(n, h).to(dev)          # per-hop stream
+    ca, ci = A.OverlapAdd(n, h).to(dev), A.OverlapAdd(n, h).to(dev)          # chunked stream (reference granularity)
+    rs = A.RealtimeSTFT(n_fft=n, hop_length=h).to(dev)
+    for c in range(3):
+        frs, ys = [], []
+        for j in range(c * chunk, (c + 1) * chunk, step):
+            fr = fa(x[:, j:j + step])
+            assert fr.shape == (2, step // h, n)
+            frs.append(fr.clone())
+            ys.append(fi.invert(rs.invert(rs(fr))))
+        fr_all, y_all = torch.cat(frs, -2), torch.cat(ys, -1)
+        frc = ca(x[:, c * chunk:(c + 1) * chunk])
+        yc = ci.invert(rs.invert(rs(frc)))
+        assert np.array_equal(cpu(fr_all), cpu(frc))
+        assert np.array_equal(cpu(fa.input_buffer), g["inbuf_%s_%d" % (key, c)])
+        if ("frames_%s_%d" % (key, c)) in g:
+            assert np.array_equal(cpu(fr_all), g["frames_%s_%d" % (key, c)])
+        assert np.array_equal(cpu(y_all), cpu(yc))                            # chunk-invariant, bit for bit
+        assert np.array_equal(cpu(fi.output_buffer), cpu(ci.output_buffer))
+        assert rel_max(cpu(y_all), g["y_%s_%d" % (key, c)]) < 1e-5
+        assert rel_max(cpu(fi.output_buffer), g["outbuf_%s_%d" % (key, c)]) < 1e-5
+
+
+def _snr_db(y, ref):
+    return 10 * np.log10((ref ** 2).sum() / max(((y - ref) ** 2).sum(), 1e-30))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_per_hop_rtpghi_golden(golden, dev, tag):
+    """The reference's RealtimeDGT driven one frame per call (G15): the module at n = 1, and the graph-captured
+    per-hop session fed the reference's recorded noise, both kept on the reference's trajectory."""
+    from acids_transforms_amd import ops
+    from acids_transforms_amd.streaming import StreamingDGTSession
+    g = golden("g15_rtpghi_per_hop")
+    n, h, nsteps, chunk = [int(v) for v in g[tag + "_params"]]
+    S, F = 2, n // 2 + 1
+    x = T_(g[tag + "_x"]).to(dev)
+    rt = A.RealtimeDGT(n_fft=n, hop_length=h, batch_size=[S]).to(dev)
+    rt.reset(torch.Size([S]))
+    sess = StreamingDGTSession(S, h, n, h, device=dev, random_phase_below_tolerance="external", use_graph=True)
+    ys = []
+    for j in range(nsteps):
+        mag_ref = g["%s_mag_%d" % (tag, j)]
+        noise = T_(g["%s_noise_%d" % (tag, j)]).to(dev)
+        ref = g["%s_yframes_%d" % (tag, j)]
+        # (1) module, one frame per call, on the golden magnitudes
+        mag = T_(mag_ref).to(dev)
+        ph = rt.pghi(mag, noise=noise)
+        frames = ops.irfft_frames(None, rt.inv_window[:n], n, mag=mag, phase=ph)
+        ops.rt_update_buffers_(mag, ph, rt.hgi_mag_buffer, rt.hgi_phase_buffer)
+        assert _snr_db(cpu(frames), ref) > 40.0, (j, _snr_db(cpu(frames), ref))
+        assert np.allclose(cpu(rt.hgi_mag_buffer), g["%s_magbuf_%d" % (tag, j)], rtol=1e-5, atol=1e-6)
+        # (2) session: audio in, audio out, one hipGraph replay per hop
+        sess.noise_in.copy_(noise)
+        ys.append(sess.step(x[:, j * h:(j + 1) * h]).clone())
+        assert rel_max(cpu(sess.mag_out), mag_ref) < 1e-5
+        assert np.allclose(cpu(sess.mag_hist), g["%s_magbuf_%d" % (tag, j)], rtol=1e-5, atol=1e-5 * float(mag_ref.max()))
+        dphi = np.angle(np.exp(1j * (cpu(sess.prev_phase) - g["%s_phasebuf_%d" % (tag, j)])))
+        big = g["%s_magbuf_%d" % (tag, j)][:, 1] > 1e-2 * g["%s_magbuf_%d" % (tag, j)].max()
+        assert np.abs(dphi[big]).max() < 5e-2, j
+        # keep both on the reference's trajectory for the next hop
+        for hist, prev in ((rt.hgi_mag_buffer, rt.hgi_phase_buffer), (sess.mag_hist, sess.prev_phase)):
+            hist.copy_(T_(g["%s_magbuf_%d" % (tag, j)]).to(dev))
+            prev.copy_(T_(g["%s_phasebuf_%d" % (tag, j)]).to(dev))
+    y = cpu(torch.cat(ys, -1))
+    assert y.shape == g[tag + "_y"].shape
+    assert _snr_db(y, g[tag + "_y"]) > 40.0, _snr_db(y, g[tag + "_y"])
+
+
+@pytest.mark.parametrize("C", [256, 1024, 4096])
+def test_streaming_session_256_streams(dev, C):
+    """BASELINE config 5 as written: 256 concurrent streams, hop-sized / 1024 / 4096-sample steps, bf16 MFMA mel
+    features, one hipGraph replay per step -- against the eager module chain on the same input."""
+    from acids_transforms_amd import ops
+    from acids_transforms_amd.streaming import StreamingDGTSession
+    S, n, h = 256, 1024, 256
+    steps = 3 if C == 4096 else 6
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(S, steps * C, generator=g) * 0.1).to(dev)
+    sess = StreamingDGTSession(S, C, n, h, device=dev, random_phase_below_tolerance=False, use_graph=True, mel_bands=128,
+                               mel_dtype="bf16")
+    assert sess.graph is not None and sess.n == C // h
+    mel32 = A.Magnitude(n_fft=n, n_mels=128, mode=None, contrast="log1p").to(dev)
+    oa, oi = A.OverlapAdd(n, h).to(dev), A.OverlapAdd(n, h).to(dev)
+    rt = A.RealtimeDGT(n_fft=n, hop_length=h, batch_size=[S]).to(dev)
+    rt.reset(torch.Size([S]))
+    for c in range(steps):
+        xc = x[:, c * C:(c + 1) * C]
+        y = sess.step(xc)
+        fr = oa(xc)
+        X = rt(fr)
+        mag = X.abs()
+        ph = rt.pghi(mag, noise=torch.zeros_like(mag))
+        frames = ops.irfft_frames(None, rt.inv_window[:n], n, mag=mag, phase=ph)
+        ops.rt_update_buffers_(mag, ph, rt.hgi_mag_buffer, rt.hgi_phase_buffer)
+        yr = oi.invert(frames)
+        assert y.shape == yr.shape == (S, C)
+        assert rel_max(cpu(y), cpu(yr)) < 1e-5, c
+        assert np.array_equal(cpu(sess.mag_hist), cpu(rt.hgi_mag_buffer))
+        assert sess.mel_out.shape == (S, C // h, 128)
+        assert rel_max(cpu(sess.mel_out), cpu(mel32(X))) < 4e-3, c          # bf16 operands: SURVEY hard part 5
+    assert bool(torch.isfinite(y).all()) and float(y.abs().max()) > 1e-3
+
+
+def test_streaming_per_hop_analysis_equals_chunked(dev):
+    """Everything chunk-invariant in the step -- magnitudes and mel features of every analysed frame -- is the same
+    whether the session is fed one hop or a 1024-sample chunk at a time (fp32 mel: 1e-5 bar, bit-identical here)."""
+    from acids_transforms_amd.streaming import StreamingDGTSession
+    S, n, h = 5, 1024, 256
+    g = torch.Generator().manual_seed(78)
+    x = (torch.randn(S, 8 * 1024, generator=g) * 0.1).to(dev)
+    a = StreamingDGTSession(S, 256, n, h, device=dev, random_phase_below_tolerance=False, mel_bands=128)
+    b = StreamingDGTSession(S, 1024, n, h, device=dev, random_phase_below_tolerance=False, mel_bands=128)
+    for c in range(8):
+        b.step(x[:, c * 1024:(c + 1) * 1024])
+        mags, mels = [], []
+        for j in range(4):
+            a.step(x[:, c * 1024 + j * 256:c * 1024 + (j + 1) * 256])
+            mags.append(a.mag_out.clone())
+            mels.append(a.mel_out.clone())
+        assert np.array_equal(cpu(torch.cat(mags, 1)), cpu(b.mag_out))
+        assert np.array_equal(cpu(torch.cat(mels, 1)), cpu(b.mel_out))
+    with pytest.raises(ValueError):
+        StreamingDGTSession(S, 300, n, h, device=dev)
