@@ -120,6 +120,21 @@ def launch_ranks(args) -> int:
 # ----------------------------------------------------------------------------------------------
 # CPU baselines (the oracle timed on this box's host cores; rank 0, N = 1 only)
 # ----------------------------------------------------------------------------------------------
+def host_cpus():
+    """Host threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands
+    one GPU's job a share of the host, not all of os.cpu_count())."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        pass
+    usable = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return {"os_cpu_count": os.cpu_count(), "affinity": n, "cgroup_quota": quota, "usable": usable}
+
+
 def cpu_baseline(threads, sample_clips, budget_s=10.0):
     """The oracle (CPU restatement: torch CPU stft + matmul + istft) on `threads` host threads, on a bounded
     sample of the same workload: STFT fwd + Magnitude(mel128) + ISTFT."""
@@ -169,7 +184,7 @@ def synth_tonal(n_clips, length, seed=7, device="cpu"):
     return out
 
 
-def cpu_baseline_pghi(mag_noise, mag_tonal, threads):
+def cpu_baseline_pghi(mag_noise, mag_tonal, thread_counts):
     """oracle/pghi_ref.c (exact-order C PGHI), one clip per host thread, on magnitudes computed by the device
     DGT (the very inputs of the GPU figure)."""
     from oracle import oracle as O
@@ -180,14 +195,17 @@ def cpu_baseline_pghi(mag_noise, mag_tonal, threads):
         m = mag.numpy()
         clips, frames = m.shape[0], m.shape[1]
         res = {}
-        for th, nclips in ((1, min(clips, 4 if tag == "noise" else 32)), (threads, clips)):
+        for th in [1] + sorted(set(thread_counts)):
+            nclips = min(clips, 4 if tag == "noise" else 32) if th == 1 else clips
             t0 = time.perf_counter()
             _, pops = O.pghi_offline_batch(m[:nclips], N_FFT, HOP, threads=th, want_pops=True)
             dt = time.perf_counter() - t0
-            res["threads_%d" % th if th == 1 else "all_cores"] = {
+            res["threads_%d" % th] = {
                 "value": nclips * frames / dt, "unit": "frames/s", "cores": th, "kind": "port", "heap_pops_per_s": pops / dt,
                 "seconds": dt, "sample": "%d clips x %d frames, %s magnitudes, exact-heap C PGHI, %d thread(s), one clip per "
                                          "thread at a time" % (nclips, frames, tag, th)}
+        best = max((k for k in res if k != "threads_1"), key=lambda k: res[k]["value"])
+        res["all_cores"] = res[best]
         out[tag] = res
     return out
 
@@ -650,11 +668,22 @@ def main():
     }
     result.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ncpu = os.cpu_count() or 1
-        result["cpu_baseline"] = cpu_baseline(ncpu, 96)
-        result["cpu_baseline_1thread"] = cpu_baseline(1, 8, budget_s=6.0)
+        hc = host_cpus()
+        result["host_cpus"] = hc
+        # torch's CPU ops do not scale to every hardware thread of the box (oversubscription beyond the job's CPU
+        # share): time a few thread counts briefly, report the best as THE baseline and keep the sweep
+        sweep = {}
+        for th in sorted({1, 8, 16, 32, 64, hc["usable"], hc["affinity"]}):
+            if th <= hc["affinity"]:
+                sweep[th] = cpu_baseline(th, 8 if th == 1 else 96, budget_s=3.0)
+        best = max(sweep, key=lambda t: sweep[t]["value"])
+        result["cpu_baseline"] = sweep[best]
+        result["cpu_baseline_1thread"] = sweep[1]
+        result["cpu_baseline_sweep"] = {str(t): round(v["value"], 1) for t, v in sweep.items()}
         if pghi_inputs:
-            result["cpu_baseline_pghi"] = cpu_baseline_pghi(pghi_inputs.get("noise"), pghi_inputs.get("tonal"), ncpu)
+            # one clip per thread: oversubscribed threads only queue, so every hardware thread we may run on is used
+            result["cpu_baseline_pghi"] = cpu_baseline_pghi(pghi_inputs.get("noise"), pghi_inputs.get("tonal"),
+                                                            [hc["usable"], 2 * hc["usable"], hc["affinity"]])
             try:
                 gpu = result["pghi_invert"]
                 cpu = result["cpu_baseline_pghi"]

@@ -2,6 +2,7 @@
 (tests/golden/g13_sinebank.npz, random phases recorded) and the oracle.  The oscillator phase is formed in fp32
 exactly as the reference does; what differs is the summation order over bins (MFMA contraction vs torch.sum)
 and sin()'s last bit -> 1e-5 of the output's largest magnitude (the output is peak-normalised to 1)."""
+import numpy as np
 import pytest
 import torch
 
