@@ -465,7 +465,7 @@ def main():
         # one kernel reads the audio and writes spectrum + features: 1024 + 4104 + 512 bytes per frame
         kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD + 4 * N_MELS), hbm_entry("istft", BYTES_ISTFT)]
         kernels[0]["kernel"] = "stft_fwd+mel (fused)"
-        if rank == 0 and not args.no_extras:
+        if rank == 0:                                            # cheap (~40 launches): kept under --no-extras too
             Xs = stft(x)
             avg["mel"] = timed_ms(lambda: mag(Xs))               # the stand-alone projection, outside the step
             del Xs

@@ -68,3 +68,13 @@ if traffic:
         print("| `%s` | %.0f | %.0f | %.1f | %.1f | %.1f |" % (k, fe, wr, rd_mb, wr_mb, rd_mb + wr_mb))
         js[k] = {"fetch_kib": fe, "write_kib": wr, "read_bytes_corrected": 2 * fe * 1024, "write_bytes": wr * 1024}
     json.dump(js, open(os.path.join(out, "pmc_traffic_%s.json" % tag), "w"), indent=1)
+    # what bench.py reports as roofline.traffic: per-launch HBM bytes of the step kernels from THIS pass
+    bt = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `%s`; FETCH_SIZE "
+                      "doubled per MI355X_MICROARCH.md (gfx950)" % tag}
+    for key, needle in (("stft_fwd", "stft1024_h256_fwd_kernel<false, 1"), ("stft_fwd_unfused", "stft1024_h256_fwd_kernel<false, 0"),
+                        ("istft", "istft1024_ola_kernel"), ("mel", "mel_banded_kernel")):
+        for k, v in js.items():
+            if needle in k:
+                bt[key] = int(round(v["read_bytes_corrected"] + v["write_bytes"], -5))
+                break
+    json.dump(bt, open(os.path.join(out, "bench_traffic_%s.json" % tag), "w"), indent=1)
