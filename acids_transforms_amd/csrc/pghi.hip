@@ -284,11 +284,19 @@ __device__ __forceinline__ u64 pack_item(float key, int idx) {
 __device__ __forceinline__ float item_key(u64 e) { return __uint_as_float((unsigned)(e >> 32)); }
 __device__ __forceinline__ int item_idx(u64 e) { return (int)(unsigned)e; }
 
+// Heap words and cell state in global memory are written and re-read by lanes of ONE wave only.  A CU's vector L1
+// is write-through and coherent for the waves of that CU, so workgroup scope is all the visibility this needs
+// (ACIDS_PGHI_SCOPE=__HIP_MEMORY_SCOPE_AGENT at compile time restores the L2-served sc1 accesses: those write
+// through to memory and DROP the line from L2 -- MI355X_MICROARCH.md, "stores of each flavour" -- so every later read
+// of a heap entry paid a trip beyond L2).  The relaxed atomics only pin the compiler's ordering.
+#ifndef ACIDS_PGHI_SCOPE
+#define ACIDS_PGHI_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 __device__ __forceinline__ u64 gload(const u64* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, ACIDS_PGHI_SCOPE);
 }
 __device__ __forceinline__ void gstore(u64* p, u64 v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, ACIDS_PGHI_SCOPE);
 }
 
 // The heap array: positions [0, cap) live in this wave's LDS (the top levels, where every pop starts),
@@ -340,8 +348,8 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src) {
   return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float fload(const float* p) {   // L2-served load of a cell another lane may have just written
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ float fload(const float* p) {   // a cell another lane of this wave may have just written
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, ACIDS_PGHI_SCOPE);
 }
 
 // place `item` at `pos` and let it rise (utils/heapq.py:9-21 with startpos = 0)
@@ -565,6 +573,291 @@ __global__ __launch_bounds__(512) void pghi_hgi_offline_coop_kernel(HgiParams p)
     o[0] = npops; o[1] = c_pop1; o[2] = c_bubble; o[3] = c_sift; o[4] = c_nb; o[5] = c_push; o[6] = n_push; o[7] = s_depth; o[8] = hn_max;
   }
 #undef TICK
+}
+
+// ---------------------------------------------------------------------------
+// K14 offline, winner-bit variant of the wave-cooperative heap (opt-in: ACIDS_PGHI_KERNEL=wbit; an experiment kept
+// runnable, NOT the default -- measured slower, see the end of this comment).
+//
+// Same array-embedded binary heap, same sift rules, same pop order -- what changes is how the pop finds its
+// bubble-up path.  Every internal node of the top 17 levels carries one "winner" bit -- 1 iff heapq.py:33 would
+// take the right child: it exists and not (left.key < right.key) -- so the path root -> leaf of a pop is read off
+// the bits by ~50 scalar instructions (three LDS words: levels 0-5, 6-11, 12-16) BEFORE any heap entry is loaded.
+// All entries the pop needs -- per level: the child that moves up, the grandchild that becomes its new value, the
+// sibling it is compared with for the new bit -- are then requested in ONE parallel round (lane k = level k),
+// where the cooperative kernel above resolves five levels per dependent round.  A push is one round too
+// (ancestors and their siblings by index).  The bits are derived data, kept exact by these rules:
+//   * a pop rewrites the bits of the nodes on its path above the slot `last` ends up in;
+//   * a push rewrites the bits of the ancestors whose chain child changed (those it passed, plus one);
+//   * a bit left pointing at a right child that was since taken off the end of the heap is recognised when the
+//     path is read (the position equals the heap's size) and sends the path to the left sibling, a leaf;
+// every bit is thus written when its node first gets a child and whenever a child's key changes (model-checked
+// against CPython's heapq with heavily tied keys before it was written in HIP).  Levels below 17 (heaps beyond
+// 262 143 entries) continue with plain child compares, one dependent round per level.
+// Outcome (profiles/r02b_pghi_kernels.md, 1024 dense clips): 2 global round trips per pop instead of ~2.3, but 477
+// instructions per pop against 360 -- and with one wave per SIMD a pop costs ~4.7 cycles per instruction whatever
+// the memory does: 0.765 s against 0.706 s.  Requesting the first push's ancestors ahead of the pop's round made it
+// slower still (the register allocator reuses the prefetch registers, which drains vmcnt early).
+// ---------------------------------------------------------------------------
+constexpr int WB_LEVELS = 17;                    // winner bits for internal nodes at levels 0..16
+constexpr int WB_T1 = 2, WB_T2 = 2 + 128;        // u32 word offsets of the tiers: [t0: 2][t1: 64 x 2][t2: 4096]
+constexpr int WB_WORDS = 2 + 128 + 4096;
+
+__device__ __forceinline__ u64 rfl64(u64 v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((u64)hi << 32) | lo;
+}
+
+// winner bit of internal node `node` (level <= 16) <- bit.  Called by single lanes; lanes of one wave may hit the
+// same word (LDS atomics).
+__device__ __forceinline__ void wb_write(unsigned* wb, int node, bool bit) {
+  const unsigned q = (unsigned)node + 1u;
+  const int lv = 31 - __clz(q);
+  const unsigned o = q - (1u << lv);
+  const int base_lv = lv < 6 ? 0 : (lv < 12 ? 6 : 12);
+  const int d = lv - base_lv;
+  const unsigned j = o >> d;                                  // tier word (the ancestor at the tier's first level)
+  const unsigned local = (1u << d) + (o & ((1u << d) - 1u));  // heap-order index inside the tier subtree, 1-based
+  const unsigned widx = lv < 6 ? (local >> 5) : (lv < 12 ? WB_T1 + 2 * j + (local >> 5) : WB_T2 + j);
+  const unsigned m = 1u << (local & 31);
+  __hip_atomic_fetch_and(wb + widx, ~m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  if (bit) __hip_atomic_fetch_or(wb + widx, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// follow the bits from the root: returns the 17 choices, first level in the top bit (scalar unit)
+__device__ __forceinline__ unsigned wb_follow(const unsigned* wb, int n) {
+  u64 w = rfl64(*reinterpret_cast<const u64*>(wb));
+  unsigned i = 1;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) i = 2 * i + (unsigned)((w >> i) & 1ull);
+  const unsigned j1 = i - 64;
+  unsigned i2 = 1, i3 = 1, j2 = j1 << 6;
+  if (n > 63) {
+    w = rfl64(*reinterpret_cast<const u64*>(wb + WB_T1 + 2 * j1));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) i2 = 2 * i2 + (unsigned)((w >> i2) & 1ull);
+    j2 = (j1 << 6) | (i2 - 64);
+    if (n > 4095) {
+      const unsigned w2 = (unsigned)__builtin_amdgcn_readfirstlane((int)wb[WB_T2 + j2]);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) i3 = 2 * i3 + ((w2 >> i3) & 1u);
+      return (j2 << 5) | (i3 - 32);
+    }
+    return j2 << 5;
+  }
+  return j1 << 11;
+}
+
+// three (two) entries per lane in one round: LDS part unconditionally, global part under one uniform test.  The
+// scheduling barriers keep the loads back to back: left alone, the scheduler slips the first load's select between
+// them and the wait that select needs turns one round trip into three.
+__device__ __forceinline__ void wb_load3(const Heap& H, int pa, bool va, int pb, bool vb, int pc, bool vc, u64 dflt,
+                                         u64& a, u64& b, u64& c) {
+  const bool ga = va && pa >= H.cap, gb = vb && pb >= H.cap, gc = vc && pc >= H.cap;
+  a = H.top[(va && !ga) ? pa : 0];
+  b = H.top[(vb && !gb) ? pb : 0];
+  c = H.top[(vc && !gc) ? pc : 0];
+  if (__ballot(ga || gb || gc)) {
+    const u64* qa = H.rest + (ga ? pa : 0);
+    const u64* qb = H.rest + (gb ? pb : 0);
+    const u64* qc = H.rest + (gc ? pc : 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const u64 xa = gload(qa);
+    const u64 xb = gload(qb);
+    const u64 xc = gload(qc);
+    __builtin_amdgcn_sched_barrier(0);
+    a = ga ? xa : a;
+    b = gb ? xb : b;
+    c = gc ? xc : c;
+  }
+  a = va ? a : dflt;
+  b = vb ? b : dflt;
+  c = vc ? c : dflt;
+}
+__device__ __forceinline__ void wb_load2(const Heap& H, int pa, bool va, int pb, bool vb, u64& a, u64& b) {
+  const bool ga = va && pa >= H.cap, gb = vb && pb >= H.cap;
+  a = H.top[(va && !ga) ? pa : 0];
+  b = H.top[(vb && !gb) ? pb : 0];
+  if (__ballot(ga || gb)) {
+    const u64* qa = H.rest + (ga ? pa : 0);
+    const u64* qb = H.rest + (gb ? pb : 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const u64 xa = gload(qa);
+    const u64 xb = gload(qb);
+    __builtin_amdgcn_sched_barrier(0);
+    a = ga ? xa : a;
+    b = gb ? xb : b;
+  }
+}
+
+// heappush (heapq.py:45-48, 9-21): `item` goes to position `pos` (= the heap's size) and rises; bits of the
+// ancestors whose chain child changed are rewritten
+__device__ __forceinline__ void wb_push(const Heap& H, unsigned* wb, int pos, u64 item, int lane) {
+  const unsigned q = (unsigned)pos + 1u;
+  const int depth = 31 - __clz(q);                // number of ancestors (<= 25)
+  const int sh = lane < 31 ? lane : 30;
+  const int my_dst = (int)(q >> sh) - 1;          // lane j: the chain node below ancestor j+1 (j = 0: pos itself)
+  const int my_anc = (int)(q >> (sh + 1)) - 1;    // lane j: ancestor j+1
+  const bool act = lane < depth;
+  const int sibp = (my_dst & 1) ? my_dst + 1 : my_dst - 1;
+  const bool sib_ok = act && sibp <= pos;         // only pos's own right sibling can be missing
+  u64 anc, sb;
+  wb_load2(H, my_anc, act, sibp, sib_ok, anc, sb);
+  const bool rises = act && (item_key(item) < item_key(anc));
+  const u64 mask = __ballot(rises);
+  const int m = (mask == ~0ull) ? 64 : __builtin_ctzll(~mask);  // item passes ancestors 1 .. m
+  if (lane <= m && lane <= depth) H.store(my_dst, lane == m ? item : anc);
+  // ancestor j+1 (lane j <= min(m, depth-1)): its chain child my_dst now holds `anc` (j < m) or the item (j == m)
+  const int anc_level = depth - 1 - lane;
+  if (act && lane <= m && anc_level < WB_LEVELS) {
+    const float nk = item_key(lane < m ? anc : item);
+    const bool bit = (my_dst & 1) ? (sib_ok && !(nk < item_key(sb))) : !(item_key(sb) < nk);
+    wb_write(wb, my_anc, bit);
+  }
+}
+
+__global__ __launch_bounds__(512) void pghi_hgi_offline_wbit_kernel(HgiParams p) {
+  const int wave = threadIdx.x >> 6;
+  const long long b = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (b >= p.B) return;
+  const int lane = threadIdx.x & 63;
+  const int T = p.T, F = p.F;
+  const long long n = (long long)T * F;
+  float* spec = p.spec + b * n;
+  const float* tg = p.tgradw + b * n;
+  const float* fg = p.fgradw + b * n;
+  float* phase = p.phase + b * n;
+  extern __shared__ __attribute__((aligned(16))) u64 heap_top[];
+  const size_t per_wave = (size_t)(p.heap_lds_cap + 1) + (WB_WORDS + 1) / 2;      // u64 units
+  u64* my_lds = heap_top + (size_t)wave * per_wave;
+  const Heap H = {my_lds, reinterpret_cast<u64*>(p.heap + b * (n + 2)), p.heap_lds_cap};
+  unsigned* wb = reinterpret_cast<unsigned*>(my_lds + p.heap_lds_cap + 1);
+  int* order = p.order ? p.order + b * n : nullptr;
+  const float abstol = p.abstol;
+  const float inv_F = 1.0f / (float)F;
+  const u64 kInf = (u64)0x7f800000u << 32;
+
+  for (long long i = lane; i < n; i += 64) phase[i] = 0.0f;  // dgt.py:170
+
+  float max_val;
+  long long max_pos;
+  clip_argmax(spec, n, abstol, 0.f, false, lane, max_val, max_pos);  // :173-174
+  const float thr = max_val * p.tol;                                   // :177-178
+  long long npops = 0;
+  if (lane == 0) {
+    H.store(0, pack_item(-max_val, (int)max_pos));  // :175
+    spec[max_pos] = abstol;                         // :176
+  }
+  int hn = 1;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+  while (max_val > abstol) {  // :179
+    while (hn > 0) {          // :180
+      hn = uni(hn);
+      // heappop, part 1 (heapq.py:51-56): take the last entry off; the root is what is returned
+      const int r = hn - 1;
+      const u64 rootv = H.top[0];
+      const u64 last = H.load(r);
+      hn -= 1;
+      const int c = (hn == 0) ? uni(item_idx(last)) : uni(item_idx(rootv));
+      if (order && lane == 0) order[npops] = c;
+      ++npops;
+      int col = (int)((float)c * inv_F);
+      int row = c - col * F;
+      if (row < 0) { row += F; col -= 1; }
+      else if (row >= F) { row -= F; col += 1; }
+      // neighbourhood (lanes 0..3: next frame, previous frame, next bin, previous bin; dgt.py:188-215), requested now
+      const int d = (lane == 0) ? F : (lane == 1) ? -F : (lane == 2) ? 1 : -1;
+      const bool inb = (lane == 0) ? (col < T - 1) : (lane == 1) ? (col > 0) : (lane == 2) ? (row < F - 1)
+                                                                                            : (lane == 3) && (row > 0);
+      const int nb = inb ? c + d : c;
+      const float* gr = (lane < 2) ? fg : tg;
+      const float s = fload(spec + nb);
+      const float g_c = gr[c];
+      const float g_n = gr[nb];
+      const float pc = fload(phase + c);
+
+      if (hn > 0) {
+        // heappop, part 2 (heapq.py:24-42): the path of smaller children from the root, read off the bits ...
+        unsigned path = wb_follow(wb, hn);
+        int plen = WB_LEVELS;                                   // levels described by `path`
+        {
+          int pos = (1 << WB_LEVELS) - 1 + (int)path;           // the level-17 node of the path
+          // ... and, below level 17, by comparing the children (heaps beyond 2^18 - 1 entries only)
+          while (pos < hn && 2 * pos + 1 < hn && plen < 31) {
+            const int cl = 2 * pos + 1;
+            const float kl = item_key(H.load(cl));
+            const bool has_r = cl + 1 < hn;
+            const float kr = has_r ? item_key(H.load(cl + 1)) : 0.f;
+            const unsigned bsel = (has_r && !(kl < kr)) ? 1u : 0u;
+            path = (path << 1) | (unsigned)uni((int)bsel);
+            pos = cl + (int)(path & 1u);
+            ++plen;
+          }
+        }
+        // lane k = level k: p_k = (2^k - 1) + (first k choices)
+        // A bit may still point at a right child that has since been taken off the end of the heap (position hn,
+        // even): its left sibling hn - 1 is then the only child, and a leaf -- the path ends there.  (Nothing else
+        // can be stale: the bit is rewritten as soon as position hn is filled again.)
+        const int k1 = lane + 1, k2 = lane + 2;
+        const int gone = (hn & 1) ? -1 : hn;
+        int p0 = lane <= plen ? (1 << lane) - 1 + (int)(path >> (plen - lane)) : 0x7fffffff;
+        int p1 = k1 <= plen ? (1 << k1) - 1 + (int)(path >> (plen - k1)) : 0x7fffffff;
+        int p2 = k2 <= plen ? (1 << k2) - 1 + (int)(path >> (plen - k2)) : 0x7fffffff;
+        p0 = p0 == gone ? hn - 1 : p0;
+        p1 = p1 == gone ? hn - 1 : p1;
+        p2 = p2 == gone ? hn - 1 : p2;
+        const int L = __builtin_popcountll(__ballot(p0 < hn)) - 1;          // the path ends at level L (a prefix is valid)
+        const bool v1 = p1 < hn, v2 = p2 < hn;
+        const int sb1 = (p1 & 1) ? p1 + 1 : p1 - 1;                          // sibling of the child that moves up
+        const bool vs = v1 && sb1 < hn;
+        u64 X1, X2, S1;
+        wb_load3(H, p1, v1, p2, v2, sb1, vs, kInf, X1, X2, S1);
+        // `last` goes into the leaf p_L and rises while it is smaller than its parent (heapq.py:39-42): past the
+        // entry that moved into p_{L-1} (the old p_L), p_{L-2}, ...  Levels below where it stops keep their entries.
+        const u64 R = __ballot(v1 && item_key(last) < item_key(X1));          // bit k: passes the old entry of p_{k+1}
+        const u64 Z = ~R & ((1ull << L) - 1ull);
+        const int m = Z ? (L - 1) - (63 - __builtin_clzll(Z)) : L;
+        const int Lp = L - m;                                                  // `last` ends up in p_{L'}
+        if (lane < Lp) H.store(p0, X1);
+        else if (lane == Lp) H.store(p0, last);
+        if (lane < Lp && lane < WB_LEVELS) {
+          const float nk = item_key(lane + 1 < Lp ? X2 : last);               // new entry of the chain child p_{k+1}
+          const bool bit = (p1 & 1) ? (vs && !(nk < item_key(S1))) : !(item_key(S1) < nk);
+          wb_write(wb, p0, bit);
+        }
+      }
+      const float half = (g_c + g_n) / 2.0f;
+      const float new_phase = (lane & 1) ? pc - half : pc + half;
+      const bool lv = inb && live(s, abstol, thr);     // inb is false on lanes >= 4
+      if (lv) {
+        phase[nb] = new_phase;
+        spec[nb] = abstol;
+      }
+      const u64 lvmask = __ballot(lv);
+      const u64 mine = pack_item(-s, nb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((lvmask >> q) & 1ull) {
+          const u64 item = readlane64(mine, q);
+          wb_push(H, wb, hn, item, lane);      // heappush (heapq.py:45-48)
+          ++hn;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // the scan below must not hit stale L1 lines
+    // :216-219 reseed from the global max of what is left (lane-parallel scan)
+    clip_argmax(spec, n, abstol, thr, true, lane, max_val, max_pos);
+    if (lane == 0) {
+      H.store(0, pack_item(-max_val, (int)max_pos));
+      spec[max_pos] = abstol;
+    }
+    hn = 1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  if (p.npops && lane == 0) p.npops[b] = npops;
 }
 
 // ---------------------------------------------------------------------------
@@ -1119,8 +1412,26 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
   HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, cap, prof, order_or_null};
   // ACIDS_PGHI_SERIAL=1 selects the single-lane reference kernel (debugging aid; identical results)
   static const bool serial = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
+  // ACIDS_PGHI_KERNEL=wbit selects the winner-bit variant (identical results; slower on every batch measured, see the
+  // comment above it and DESIGN.md 3.4 -- kept selectable so that the parity tests and tools/fuzz_pghi.py can run it)
+  static const bool use_coop = [] { const char* e = getenv("ACIDS_PGHI_KERNEL"); return !(e && e[0] == 'w'); }();
   if (serial) {
     hipLaunchKernelGGL(pghi_hgi_offline_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
+  } else if (!use_coop && !prof) {
+    // winner-bit kernel: per clip 16.5 KB of bits + the heap's top levels in LDS; at most 8 clips resident per CU
+    const int wcap = per_cu <= 4 ? 2047 : per_cu <= 6 ? 1023 : 255;
+    h.heap_lds_cap = wcap;
+    const size_t per_wave = sizeof(u64) * ((size_t)(wcap + 1) + (WB_WORDS + 1) / 2);
+    int wpb = per_cu >= 8 ? 8 : per_cu >= 4 ? 4 : per_cu >= 2 ? 2 : 1;
+    while (wpb > 1 && per_wave * wpb > 160 * 1024 - 512) wpb >>= 1;
+    const size_t block_lds = per_wave * wpb;
+    if (block_lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)pghi_hgi_offline_wbit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)block_lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return AT_ELAUNCH;
+    }
+    hipLaunchKernelGGL(pghi_hgi_offline_wbit_kernel, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(64 * wpb), block_lds, s, h);
   } else {
     void (*kernel)(HgiParams) = prof ? pghi_hgi_offline_coop_kernel<true> : pghi_hgi_offline_coop_kernel<false>;
     // waves per workgroup: as many (<= 8) as keep the workgroup's heap tops within the CU's 160 KB
