@@ -259,7 +259,8 @@ def test_fused_reference_default_chain(dev):
     fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 513, 44100))
     off, sc = O.magnitude_scale_stats(Xr, "log1p", "unipolar")
     assert rel_max(cpu(y), O.magnitude_forward(Xr, fwd, "log1p", off, sc).numpy()) < TOL
-    assert float(y[..., 0].abs().max()) == float(y2[..., 0].abs().max())      # empty filters: contrast(0), normalised
+    # empty filters: contrast(0), normalised (the fused epilogue multiplies by 1/scale where the stand-alone kernel divides)
+    assert abs(float(y[..., 0].abs().max()) - float(y2[..., 0].abs().max())) <= 1e-6 * float(y2[..., 0].abs().max())
 
 
 def test_fused_random_banded_bank(dev):
