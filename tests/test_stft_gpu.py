@@ -315,3 +315,32 @@ def test_every_power_of_two_size(dev, n):
             assert X.shape == Xr.shape and rel_max(cpu(X), Xr.numpy()) < TOL, (hop, cls.__name__)
             y, yr = t.invert(X), O.istft(Xr, t.inv_window[:n].cpu(), n, hop)
             assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL, (hop, cls.__name__)
+
+
+def test_bench_step_at_full_batch_vs_oracle(dev):
+    """What bench.py times, at its size: B = 1024 clips x 4 s through the fused STFT+mel forward and the ISTFT; the
+    launchers cut 1024 clips into runs by occupancy, so clips from both ends and the middle are checked against the
+    oracle (the headline number must be a number on verified output)."""
+    B, L = 1024, 176400
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    x = torch.randn(B, L, device=dev, generator=gen) * 0.1
+    stft = A.STFT().to(dev)
+    mag = A.Magnitude(n_mels=128, mode="unipolar", contrast="log1p").to(dev)
+    mag.scale_data(stft(x[:8]))
+    assert mag.can_fuse_with(stft, x)
+    X, feat = mag.forward_fused(stft, x, return_spectrum=True)
+    y = stft.invert(X)
+    assert X.shape == (B, 690, 513) and feat.shape == (B, 690, 128) and y.shape == (B, 176384)
+    ids = [0, 511, 1023]
+    xs = x[ids].cpu()
+    w = O.hann_window(1024)
+    Xr = O.stft_forward(xs, w, 1024, 256)
+    fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100))
+    fr = O.magnitude_forward(Xr, fwd, "log1p", float(mag.norm.offset), float(mag.norm.scale))
+    yr = O.istft(Xr, w, 1024, 256)
+    assert rel_max(cpu(X[ids]), Xr.numpy()) < TOL
+    assert rel_max(cpu(feat[ids]), fr.numpy()) < TOL
+    assert rel_max(cpu(y[ids]), yr.numpy()) < TOL
+    # and the stage-by-stage path produces the same spectrum bit for bit / the same features within the bar
+    assert torch.equal(stft(x[1000:1008]), X[1000:1008])
+    assert rel_max(cpu(mag(X[1000:1008])), cpu(feat[1000:1008])) < TOL
