@@ -12,6 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ACIDS_HIP_LIB") or os.path.join(_HERE, "libacids_hip.so")   # override: kernel A/B experiments
 
+ABI_VERSION = 2            # what this binding was written against (include/acids_hip.h, at_abi_version())
+
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
@@ -104,6 +106,9 @@ def lib():
             fn = getattr(L, name)   # AttributeError if the .so is stale: fail loudly
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
+        if L.at_abi_version() != ABI_VERSION:
+            raise AcidsHipError("%s exports ABI version %d, this binding needs %d: rebuild it (make -C acids_transforms_amd/csrc)"
+                                % (_SO, L.at_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

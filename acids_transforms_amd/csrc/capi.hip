@@ -58,7 +58,7 @@ using namespace at_hip;
 
 extern "C" {
 
-int at_abi_version(void) { return 1; }
+int at_abi_version(void) { return 2; }   // 2: at_sinebank_realtime takes the synthesis window; bf16 projection, at_oadd_push
 
 const char* at_error_string(int code) {
   switch (code) {

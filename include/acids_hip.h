@@ -35,6 +35,7 @@ extern "C" {
 #define AT_EWORKSPACE (-4) /* workspace too small */
 #define AT_ELAUNCH (-5)    /* HIP launch / runtime error */
 
+/* 2 since round 2 (at_sinebank_realtime gained the window argument; at_mel_*bf16*, at_oadd_push added) */
 int at_abi_version(void);
 const char *at_error_string(int code);
 
