@@ -41,6 +41,11 @@ if "inv" in which:
 if "mel128" in which:
     mg = A.Magnitude(n_mels=128, mode=None).to(dev)
     report("mel128", timeit(lambda: mg(X)), 4104 + 512, 2 * 513 * 128)
+if "melbf16" in which:
+    mgb = A.Magnitude(n_mels=128, mode=None, bank_dtype="bf16").to(dev)      # dense bf16 MFMA contraction (config 5)
+    report("mel128 bf16 MFMA", timeit(lambda: mgb(X)), 4104 + 512, 2 * 513 * 128)
+    mgb5 = A.Magnitude(mode=None, bank_dtype="bf16").to(dev)
+    report("mel513 bf16 MFMA", timeit(lambda: mgb5(X), n=5), 4104 + 2052, 2 * 513 * 513)
 if "mel513" in which:
     mg = A.Magnitude(mode=None).to(dev)
     report("mel513", timeit(lambda: mg(X), n=5), 4104 + 2052, 2 * 513 * 513)

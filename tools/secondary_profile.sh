@@ -5,7 +5,7 @@ TAG=${1:-r01}
 REPO=$(pwd); OUT=$REPO/gpurun_out/sec_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o sec -- python3 $REPO/tools/perf_all.py fwd,inv,polar,mel128,mel513,fused513,fused2,mfcc40,phase,polarfwd,stftpolar,sinebank > $OUT/perf_all.log 2> $OUT/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o sec -- python3 $REPO/tools/perf_all.py fwd,inv,polar,mel128,melbf16,mel513,fused513,fused2,mfcc40,phase,polarfwd,stftpolar,sinebank > $OUT/perf_all.log 2> $OUT/err.log
 cd $REPO
 python3 - "$OUT" "$TAG" > gpurun_out/secondary_$TAG.md <<'PY'
 import csv, glob, sys, os
@@ -17,7 +17,7 @@ for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("at_hip::", "")
     d[n[:80]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("# rocprofv3 kernel trace of the kernels outside the bench step (`%s`)\n" % tag)
-print("Command: `rocprofv3 --kernel-trace --stats -- python3 tools/perf_all.py fwd,inv,polar,mel128,mel513,fused513,fused2,"
+print("Command: `rocprofv3 --kernel-trace --stats -- python3 tools/perf_all.py fwd,inv,polar,mel128,melbf16,mel513,fused513,fused2,"
       "mfcc40,phase,polarfwd,stftpolar,sinebank` at 1024 clips x 690 frames x 513 bins, one MI355X.  `steady` = mean of "
       "the fastest three quarters of the calls (the first launches of a process run on cold clocks).\n")
 print("| kernel | calls | avg us | steady us | min us |")
