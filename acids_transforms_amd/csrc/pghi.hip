@@ -144,6 +144,7 @@ struct HgiParams {
   float abstol, tol;
   long long* npops;     // optional (B) number of pops per clip
   int heap_lds_cap;     // heap entries kept in LDS per clip (2^k - 1)
+  int seg_cap;          // cooperative kernel: segment maxima kept in LDS per clip (reseeding), behind the heap's top
   int prof;             // dev only (ACIDS_PGHI_PROF=1): cycle counters go to `order` instead of the pop order
   int* order;           // optional (B, T*F) pop order (row*F+col), for the parity tests
 };
@@ -152,22 +153,144 @@ struct HgiParams {
 // (dgt.py:177-178); here that threshold is applied when a cell is read.
 __device__ __forceinline__ bool live(float v, float abstol, float thr) { return v > abstol && !(v < thr); }
 
-// global (value, first row-major index) maximum over the live cells of one clip
+// global (value, first row-major index) maximum over the live cells of one clip.  Eight independent loads per trip:
+// a plain one-load loop pays a full memory round trip per 64 cells (2.5 ms per scan of a 4-second clip).
 __device__ __forceinline__ void clip_argmax(const float* spec, long long n, float abstol, float thr, bool use_thr,
                                             int lane, float& best, long long& besti) {
   float v = -1.0f;
   long long vi = n;
-  for (long long i = lane; i < n; i += 64) {
-    float s = spec[i];
-    if (use_thr && s < thr) s = abstol;
-    if (s > v) {
-      v = s;
-      vi = i;
+  for (long long base = 0; base < n; base += 512) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = base + lane + 64 * u;
+      x[u] = spec[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = base + lane + 64 * u;
+      float sv = x[u];
+      if (use_thr && sv < thr) sv = abstol;
+      if (i < n && sv > v) {
+        v = sv;
+        vi = i;
+      }
     }
   }
   wave_argmax(v, vi);
   best = v;
   besti = vi;
+}
+
+// ---- reseeding without rescanning the clip -------------------------------------------------------------------
+// dgt.py:216-219 takes the global maximum of what is left every time the heap runs empty; a decaying sound does that
+// hundreds of times per clip (301 seeds in one second of decaying noise), and a full scan of a
+// 4-second clip is 354 k cells.  The clip is cut into S <= seg_cap segments of SL cells (row-major order) with an
+// UPPER BOUND of each segment's live maximum in LDS: exact at the start, stale-high afterwards (the flood only
+// lowers cells).  A reseed takes the first segment holding the largest bound, rescans that one segment, and is done
+// if the bound was exact -- every earlier segment has a smaller bound, every later one at most the same -- otherwise
+// it repairs the bound and repeats.  The result is the full scan's (value, first row-major index), cell for cell.
+struct SegMax {
+  float* m;        // LDS, S entries
+  int S;
+  long long SL;    // cells per segment (multiple of 512)
+};
+
+// maximum of a non-negative value over the wave (DPP row reduction + row broadcasts), valid on every lane
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  int x = (int)__float_as_uint(v);
+  auto mx = [](int a, int b) { return (int)__float_as_uint(fmaxf(__uint_as_float((unsigned)a), __uint_as_float((unsigned)b))); };
+  x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true));   // row_shr:1
+  x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true));   // row_shr:2
+  x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true));   // row_shr:4
+  x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true));   // row_shr:8  -> lane 15 of each row
+  x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
+  x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2, 3 -> lane 63
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane(x, 63));
+}
+
+// one segment: (value, first index) maximum under the threshold rule (use_thr) -- at most SL / 64 cells per lane
+__device__ __forceinline__ void seg_scan(const float* spec, long long lo, long long hi, float abstol, float thr, bool use_thr,
+                                         int lane, float& v, long long& vi) {
+  for (long long base = lo; base < hi; base += 512) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = base + lane + 64 * u;
+      x[u] = spec[i < hi ? i : hi - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = base + lane + 64 * u;
+      float sv = x[u];
+      if (use_thr && sv < thr) sv = abstol;
+      if (i < hi && sv > v) {
+        v = sv;
+        vi = i;
+      }
+    }
+  }
+}
+
+// exact bounds for every segment (+ the clip's global maximum): the first scan (use_thr = false), and the repair of
+// last resort when a reseed keeps hitting stale bounds
+__device__ __forceinline__ void seg_rebuild(const float* spec, long long n, const SegMax& G, float abstol, float thr,
+                                            bool use_thr, int lane, float& best, long long& besti) {
+  float bv = -1.0f;
+  long long bi = n;
+  for (int sg = 0; sg < G.S; ++sg) {
+    const long long lo = sg * G.SL, hi = (lo + G.SL < n) ? lo + G.SL : n;
+    float v = -1.0f;
+    long long vi = n;
+    seg_scan(spec, lo, hi, abstol, thr, use_thr, lane, v, vi);
+    const float sm = wave_max_nonneg(fmaxf(v, 0.0f));
+    if (lane == 0) G.m[sg] = sm;
+    if (v > bv) {      // per lane: cells are visited in increasing index order, so `>` keeps the first index
+      bv = v;
+      bi = vi;
+    }
+  }
+  wave_argmax(bv, bi);
+  best = bv;
+  besti = bi;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+__device__ __forceinline__ void seg_reseed(const float* spec, long long n, const SegMax& G, float abstol, float thr,
+                                           int lane, float& max_val, long long& max_pos) {
+  for (int tries = 0;; ++tries) {
+    if (tries == 48) {      // many stale bounds in a row (e.g. the one reseed at the end of a dense clip): rebuild them all
+      seg_rebuild(spec, n, G, abstol, thr, true, lane, max_val, max_pos);
+      return;
+    }
+    float bv = -1.0f;
+    long long bs = G.S;
+    for (int sg = lane; sg < G.S; sg += 64) {
+      const float x = G.m[sg];
+      if (x > bv) {
+        bv = x;
+        bs = sg;
+      }
+    }
+    wave_argmax(bv, bs);
+    if (!(bv > abstol)) {   // nothing live anywhere: the caller's loop ends (any in-range position will do)
+      max_val = abstol;
+      max_pos = 0;
+      return;
+    }
+    const long long lo = bs * G.SL, hi = (lo + G.SL < n) ? lo + G.SL : n;
+    float tv = -1.0f;
+    long long ti = n;
+    seg_scan(spec, lo, hi, abstol, thr, true, lane, tv, ti);
+    wave_argmax(tv, ti);
+    if (tv == bv) {
+      max_val = tv;
+      max_pos = ti;
+      return;
+    }
+    if (lane == 0) G.m[bs] = tv;   // stale-high bound repaired; try again
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
 }
 
 __global__ __launch_bounds__(64) void pghi_hgi_offline_kernel(HgiParams p) {
@@ -457,8 +580,14 @@ __global__ __launch_bounds__(512) void pghi_hgi_offline_coop_kernel(HgiParams p)
   const float* fg = p.fgradw + b * n;
   float* phase = p.phase + b * n;
   extern __shared__ __attribute__((aligned(16))) u64 heap_top[];
-  const Heap H = {heap_top + (size_t)wave * (p.heap_lds_cap + 1), reinterpret_cast<u64*>(p.heap + b * (n + 2)),
-                  p.heap_lds_cap};
+  const size_t per_wave = (size_t)(p.heap_lds_cap + 1) + (size_t)(p.seg_cap + 1) / 2;     // u64 units: heap top, segment maxima
+  u64* my_lds = heap_top + (size_t)wave * per_wave;
+  const Heap H = {my_lds, reinterpret_cast<u64*>(p.heap + b * (n + 2)), p.heap_lds_cap};
+  SegMax G;
+  G.m = reinterpret_cast<float*>(my_lds + p.heap_lds_cap + 1);
+  G.SL = 512 * ((n + 512LL * p.seg_cap - 1) / (512LL * p.seg_cap));
+  if (G.SL < 512) G.SL = 512;
+  G.S = (int)((n + G.SL - 1) / G.SL);
   const u64 anc_mask = chain_mask(lane);
   int* order = p.order ? p.order + b * n : nullptr;
   const float abstol = p.abstol;
@@ -468,7 +597,7 @@ __global__ __launch_bounds__(512) void pghi_hgi_offline_coop_kernel(HgiParams p)
 
   float max_val;
   long long max_pos;
-  clip_argmax(spec, n, abstol, 0.f, false, lane, max_val, max_pos);  // :173-174
+  seg_rebuild(spec, n, G, abstol, 0.f, false, lane, max_val, max_pos);  // :173-174 (+ the segment bounds)
   const float thr = max_val * p.tol;                                   // :177-178
   long long npops = 0;
   long long c_pop1 = 0, c_bubble = 0, c_sift = 0, c_nb = 0, c_push = 0, n_push = 0, s_depth = 0, hn_max = 0;
@@ -559,7 +688,7 @@ __global__ __launch_bounds__(512) void pghi_hgi_offline_coop_kernel(HgiParams p)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // the scan below must not hit stale L1 lines
     // :216-219 reseed from the global max of what is left (lane-parallel scan)
-    clip_argmax(spec, n, abstol, thr, true, lane, max_val, max_pos);
+    seg_reseed(spec, n, G, abstol, thr, lane, max_val, max_pos);
     if (lane == 0) {
       H.store(0, pack_item(-max_val, (int)max_pos));
       spec[max_pos] = abstol;
@@ -1408,8 +1537,11 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
   }
   const long long per_cu = (B + cus - 1) / cus;
   const int cap = per_cu <= 1 ? 16383 : per_cu <= 2 ? 8191 : per_cu <= 4 ? 4095 : per_cu <= 8 ? 2047 : per_cu <= 16 ? 1023 : 511;
-  const size_t heap_lds = sizeof(u64) * (size_t)(cap + 1);
-  HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, cap, prof, order_or_null};
+  // segment maxima for the reseeds (cooperative kernel), behind the heap's top: as many as keep per_cu clips resident
+  const int seg_cap = per_cu <= 4 ? 1024 : per_cu <= 8 ? 512 : 192;
+  const size_t heap_lds = sizeof(u64) * ((size_t)(cap + 1) + (size_t)(seg_cap + 1) / 2);
+  HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, cap, seg_cap, prof,
+                 order_or_null};
   // ACIDS_PGHI_SERIAL=1 selects the single-lane reference kernel (debugging aid; identical results)
   static const bool serial = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
   // ACIDS_PGHI_KERNEL=wbit selects the winner-bit variant (identical results; slower on every batch measured, see the

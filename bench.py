@@ -184,12 +184,12 @@ def synth_tonal(n_clips, length, seed=7, device="cpu"):
     return out
 
 
-def cpu_baseline_pghi(mag_noise, mag_tonal, thread_counts):
+def cpu_baseline_pghi(mags, thread_counts):
     """oracle/pghi_ref.c (exact-order C PGHI), one clip per host thread, on magnitudes computed by the device
     DGT (the very inputs of the GPU figure)."""
     from oracle import oracle as O
     out = {}
-    for tag, mag in (("noise", mag_noise), ("tonal", mag_tonal)):
+    for tag, mag in mags.items():
         if mag is None:
             continue
         m = mag.numpy()
@@ -524,12 +524,14 @@ def main():
         dgt = A.DGT(sr=SR, n_fft=N_FFT, hop_length=HOP).to(dev)
         pg = {}
         sizes = sorted({min(args.pghi_clips, B), min(4 * args.pghi_clips, 4096)})
-        for tag in ("noise", "tonal"):
+        for tag in ("noise", "tonal", "decaying"):
             for nb in (sizes if tag == "noise" else sizes[:1]):
                 if tag == "noise":
                     xs = x if nb <= B else torch.randn(nb, CLIP_LEN, device=dev, generator=gen) * 0.1
-                else:
+                elif tag == "tonal":
                     xs = synth_tonal(nb, CLIP_LEN, device=dev)
+                else:   # SURVEY Appendix B's third workload: noise x exp(-8 t) -- hundreds of reseeds per clip
+                    xs = x[:nb] * torch.exp(-8.0 * torch.arange(CLIP_LEN, device=dev, dtype=torch.float32) / SR)
                 m = dgt(xs[:nb]).abs()
                 if nb == sizes[0]:
                     collect[tag] = m[:256].cpu()              # the CPU baseline runs on the same magnitudes
@@ -546,6 +548,7 @@ def main():
                                                  "heap_pops_per_s": pops / dt, "bins_above_tolerance": pops / m.numel()}
                 del m, yp, xs
         pg["input"] = ("noise: |DGT(randn*0.1)|, ~100% of bins above tolerance; tonal: 8 decaying sinusoids per clip; "
+                       "decaying: noise x exp(-8 t), ~10% of bins, ~300 reseeds per clip; "
                        "DGT.invert(mag, 'pghi') = gradients + heap integration + polar ISTFT")
         return pg
 
@@ -682,8 +685,7 @@ def main():
         result["cpu_baseline_sweep"] = {str(t): round(v["value"], 1) for t, v in sweep.items()}
         if pghi_inputs:
             # one clip per thread: oversubscribed threads only queue, so every hardware thread we may run on is used
-            result["cpu_baseline_pghi"] = cpu_baseline_pghi(pghi_inputs.get("noise"), pghi_inputs.get("tonal"),
-                                                            [hc["usable"], 2 * hc["usable"], hc["affinity"]])
+            result["cpu_baseline_pghi"] = cpu_baseline_pghi(pghi_inputs, [hc["usable"], 2 * hc["usable"], hc["affinity"]])
             try:
                 gpu = result["pghi_invert"]
                 cpu = result["cpu_baseline_pghi"]

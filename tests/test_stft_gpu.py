@@ -208,6 +208,14 @@ def test_results_do_not_depend_on_the_batch(dev):
     alone = d.invert(m1, inversion_mode="pghi")[0]          # 16383-entry LDS heap top (checked against the oracle
     for B in (300, 700, 1100, 2100, 4200):                   # elsewhere); 8191, 4095, 2047, 1023 and 511 entries
         assert torch.equal(alone, d.invert(mb[:B], inversion_mode="pghi")[0]), B
+    # a decaying clip reseeds hundreds of times: the segment bounds behind the reseeds (1024, 512 or 192 segments per
+    # clip, by batch size) must not show either
+    xd = x0 * torch.exp(-8.0 * torch.arange(40000, device=dev) / 44100.0)
+    md = d(xd).abs()
+    alone = d.pghi(md)[0]
+    assert int((alone == 0).sum()) > 1000                     # many bins under the tolerance: a sparse flood
+    for B in (700, 1100, 2100):
+        assert torch.equal(alone, d.pghi(torch.cat([md, mb[1:B]]))[0]), B
 
 
 @pytest.mark.gpu
