@@ -26,14 +26,31 @@ int launch_rfft_generic(const float*, long long, long long, long long, long long
 int launch_irfft_generic(const float2*, const float*, const float*, long long, int, const float*, float*,
                          hipStream_t);
 int launch_ola_gather(const float*, long long, long long, int, int, const float*, float*, hipStream_t);
+// stft2048.hip
+int launch_stft2048_fwd(const float*, long long, long long, long long, long long, int, int, const float*, const float2*,
+                        const float2*, float2*, float*, hipStream_t);
+int launch_irfft2048_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
+                            const float2*, float*, hipStream_t);
+// stft512.hip
+int launch_stft512_fwd(const float*, long long, long long, long long, long long, int, int, const float*, const float2*,
+                       const float2*, float2*, float*, hipStream_t);
+int launch_irfft512_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
+                           const float2*, float*, hipStream_t);
 
 constexpr int kMaxDevices = 16;
 static float2* g_twiddles[kMaxDevices] = {nullptr};
+static float2* g_tw2048[kMaxDevices] = {nullptr};     // W2048^k, k = 0 .. 1023 (stft2048.hip), then W512^k, k = 0 .. 255 (stft512.hip)
 
 static const float2* twiddles_for_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
   return g_twiddles[dev];
+}
+
+static const float2* tw2048_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  return g_tw2048[dev];
 }
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -97,7 +114,25 @@ int at_init(int device) {
   if (hipMalloc((void**)&d, sizeof(float2) * kTwiddleCount) != hipSuccess) rc = AT_ELAUNCH;
   if (rc == AT_OK && hipMemcpy(d, tab.data(), sizeof(float2) * kTwiddleCount, hipMemcpyHostToDevice) != hipSuccess)
     rc = AT_ELAUNCH;
-  if (rc == AT_OK) g_twiddles[device] = d;
+  float2* d2 = nullptr;
+  if (rc == AT_OK) {
+    std::vector<float2> t2(1024 + 256);
+    for (int k = 0; k < 1024; ++k) {
+      const double a = -two_pi * (double)k / 2048.0;
+      t2[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    for (int k = 0; k < 256; ++k) {
+      const double a = -two_pi * (double)k / 512.0;
+      t2[1024 + k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    if (hipMalloc((void**)&d2, sizeof(float2) * t2.size()) != hipSuccess) rc = AT_ELAUNCH;
+    if (rc == AT_OK && hipMemcpy(d2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice) != hipSuccess)
+      rc = AT_ELAUNCH;
+  }
+  if (rc == AT_OK) {
+    g_tw2048[device] = d2;
+    g_twiddles[device] = d;
+  }
   (void)hipSetDevice(prev);
   return rc;
 }
@@ -117,6 +152,18 @@ int at_stft_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, i
       return launch_stft1024_h256_fwd(x, B, L, clip_stride, T, window, tw, (float2*)out_complex, phase, nullptr,
                                       nullptr, nullptr, nullptr, 0.f, 0, 0, 0, s, nullptr, hop);
     return launch_stft1024_fwd(x, B, L, clip_stride, T, hop, center, window, tw, (float2*)out_complex, phase, s);
+  }
+  if (n_fft == 2048 && (((uintptr_t)window) & 15) == 0) {      // two 512-point register FFTs + a radix-2 stage per frame
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_stft2048_fwd(x, B, L, clip_stride, T, hop, center, window, tw, tw2k, (float2*)out_complex, phase, s);
+  }
+  if (n_fft == 512 && (((uintptr_t)window) & 7) == 0) {        // two frames per 512-point register FFT
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_stft512_fwd(x, B, L, clip_stride, T, hop, center, window, tw, tw2k + 1024, (float2*)out_complex, phase, s);
   }
   return launch_rfft_generic(x, B, L, clip_stride, T, n_fft, hop, center, window, (float2*)out_complex, phase, s);
 }
@@ -216,7 +263,20 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
   }
   size_t need = (size_t)B * (size_t)T * (size_t)n_fft * sizeof(float);
   if (!workspace || workspace_bytes < need) return AT_EWORKSPACE;
-  int rc = launch_irfft_generic((const float2*)X_complex, mag, phase, B * T, n_fft, inv_window, (float*)workspace, s);
+  int rc;
+  if (n_fft == 2048 && (((uintptr_t)inv_window) & 15) == 0 && (((uintptr_t)workspace) & 15) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    rc = launch_irfft2048_frames((const float2*)X_complex, mag, phase, B * T, inv_window, tw, tw2k, (float*)workspace, s);
+  } else if (n_fft == 512 && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)workspace) & 7) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    rc = launch_irfft512_frames((const float2*)X_complex, mag, phase, B * T, inv_window, tw, tw2k + 1024, (float*)workspace, s);
+  } else {
+    rc = launch_irfft_generic((const float2*)X_complex, mag, phase, B * T, n_fft, inv_window, (float*)workspace, s);
+  }
   if (rc) return rc;
   return launch_ola_gather((const float*)workspace, B, T, n_fft, hop, inv_window, y, s);
 }
@@ -249,6 +309,18 @@ int at_irfft_frames(const float* X_complex, const float* mag, const float* phase
     const float2* tw = twiddles_for_current_device();
     if (!tw) return AT_ENOTINIT;
     return launch_irfft1024_frames((const float2*)X_complex, mag, phase, nframes, inv_window, tw, frames, s);
+  }
+  if (n_fft == 2048 && (((uintptr_t)inv_window) & 15) == 0 && (((uintptr_t)frames) & 15) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_irfft2048_frames((const float2*)X_complex, mag, phase, nframes, inv_window, tw, tw2k, frames, s);
+  }
+  if (n_fft == 512 && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)frames) & 7) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_irfft512_frames((const float2*)X_complex, mag, phase, nframes, inv_window, tw, tw2k + 1024, frames, s);
   }
   return launch_irfft_generic((const float2*)X_complex, mag, phase, nframes, n_fft, inv_window, frames, s);
 }

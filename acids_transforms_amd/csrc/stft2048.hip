@@ -1,0 +1,281 @@
+// stft2048.hip -- n_fft = 2048 on the one-wavefront register FFT core (fft512.h).
+//
+// Replaces, for n_fft = 2048 (any hop):
+//   torch.stft(...).transpose(-2,-1)          reference transforms/stft.py:98-104, dgt.py:64-70
+//   torch.fft.rfft(x*window) on frames        stft.py:249-253, dgt.py:285-289
+//   torch.fft.irfft(X) * inv_window           stft.py:260-266, dgt.py:296-302; the frames of torch.istft
+//                                             (stft.py:120-128), overlap-added by stft_generic.hip's gather
+// Until round 2 this size ran on the workgroup-per-frame LDS Stockham kernel of stft_generic.hip (~1.4 TB/s).
+//
+// A 2048-point real transform is a 1024-point complex FFT of z[n] = x[2n] + i x[2n+1] plus the real split; the
+// 1024-point FFT is two 512-point FFTs (the wave-level radix-8 core: 8 complex points per lane) of the even and the
+// odd complex samples plus one radix-2 stage:
+//   ze[m] = z[2m]   = x[4m]   + i x[4m+1]        -> one float4 load per lane and register holds (ze, zo) of the
+//   zo[m] = z[2m+1] = x[4m+2] + i x[4m+3]           same m: 1 KB contiguous per wave instruction
+//   Z[k] = Ze[k] + W1024^k Zo[k],  Z[k+512] = Ze[k] - W1024^k Zo[k]     (k = lane + 64 m: lane-local)
+//   X[k] = (Z[k] + conj Z[1024-k])/2 - (i/2) W2048^k (Z[k] - conj Z[1024-k]),  k = 0 .. 1024
+// The mirror partner Z[1024-k] lives in lane 64-lane, register 15-m (lane 0: its own register 16-m).  The inverse
+// runs the same steps backwards.  One wave = one frame at a time, frames of a block interleaved over its four
+// waves, the next frame's loads issued before the current frame's FFTs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/acids_hip.h"
+#include "fastmath.h"
+#include "fft512.h"
+
+namespace at_hip {
+
+constexpr int N2K = 2048;
+constexpr int F2K = N2K / 2 + 1;     // 1025
+constexpr int W2K = 4;               // waves per block
+
+struct P2k {
+  const float* x;        // forward: audio, clip b at x + b*clip_stride
+  const float* window;   // 2048 samples (analysis or synthesis)
+  const float2* tw;      // fft512 twiddle table (capi.hip)
+  const float2* tw2k;    // W2048^k, k = 0 .. 1023
+  float2* X;             // (frames, 1025) complex64: forward output / inverse input
+  const float* mag;      // inverse, polar input
+  const float* phase;
+  float* phase_out;      // forward: optional angle output (frames, 1025)
+  float* y;              // inverse: (frames, 2048) windowed time frames
+  long long L, clip_stride, T, total_frames, frames_per_block;
+  int hop, center;
+};
+
+__device__ __forceinline__ long long reflect2k(long long i, long long L) {
+  if (i < 0) i = -i;
+  if (i >= L) i = 2 * (L - 1) - i;
+  return i;
+}
+
+// q[j] = x[s + 4 (lane + 64 j) .. + 3] of frame f (reflect padding with center, zero padding without)
+__device__ __forceinline__ void load_frame2k(const P2k& p, long long f, int lane, float4 (&q)[8]) {
+  const long long b = f / p.T, t = f - b * p.T;
+  const float* clip = p.x + b * p.clip_stride;
+  const long long start = t * (long long)p.hop - (p.center ? N2K / 2 : 0);
+  const bool interior = (start >= 0) && (start + N2K <= p.L);
+  if (interior && ((((uintptr_t)(clip + start)) & 15) == 0)) {
+    const float4* src = reinterpret_cast<const float4*>(clip + start);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = src[lane + 64 * j];
+  } else if (interior) {
+    const float* src = clip + start;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = 4 * (lane + 64 * j);
+      q[j] = make_float4(src[i], src[i + 1], src[i + 2], src[i + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long i0 = start + 4 * (lane + 64 * j);
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long long i = i0 + c;
+        if (p.center) v[c] = clip[reflect2k(i, p.L)];
+        else v[c] = (i >= 0 && i < p.L) ? clip[i] : 0.0f;     // zero padding past the end (utils/misc.py:156)
+      }
+      q[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// mirror partners P[m] = Z[(1024 - (lane + 64 m)) mod 1024] of the 16 registers
+__device__ __forceinline__ void mirror1024(const v2f (&v)[16], v2f (&p)[16], int lane) {
+  const int src = (64 - lane) & 63;
+  v2f q[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    q[m].x = __shfl(v[m].x, src, 64);
+    q[m].y = __shfl(v[m].y, src, 64);
+  }
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const v2f a = q[15 - m];            // lane > 0: lane 64 - lane, register 15 - m
+    const v2f b = q[(16 - m) & 15];     // lane 0: own register (16 - m) mod 16
+    p[m] = (lane == 0) ? b : a;
+  }
+}
+
+// Both kernels keep the constant tables in LDS, shared by the block's four waves and read at the point of use (the
+// fft512 twiddles: 11 KB; W2048^k: 8 KB): held in registers they cost 76 VGPRs and leave one wave per SIMD.
+template <bool INV>
+__device__ __forceinline__ void stage_tables2k(const P2k& p, float2* tab, float2* w2tab) {
+  for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * W2K) tab[i] = twiddle_for_lds<INV>(p.tw, i);
+  for (int i = threadIdx.x; i < 1024; i += 64 * W2K) w2tab[i] = p.tw2k[i];
+  __syncthreads();
+}
+
+template <bool WRITE_PHASE>
+__global__ __launch_bounds__(64 * W2K, 3) void stft2048_fwd_kernel(P2k p) {
+  __shared__ float2 lds_all[W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* tab = lds_all + W2K * kFftLdsFloat2PerWave;
+  const v2f* w2 = reinterpret_cast<const v2f*>(tab + kTwiddleCount) + lane;     // w2[64 m] = W2048^(lane + 64 m)
+  stage_tables2k<false>(p, tab, tab + kTwiddleCount);
+  const LdsTwiddles<false> tw = {tab, lane};     // tw.getr(m) = W1024^(lane + 64 m) / 2
+  const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
+  long long f_end = f_begin + p.frames_per_block;
+  if (f_end > p.total_frames) f_end = p.total_frames;
+  const float4* win4 = reinterpret_cast<const float4*>(p.window);
+  const v2f hh = {0.5f, 0.5f};
+
+  long long f = f_begin + wave;
+  float4 nxt[8];
+  if (f < f_end) load_frame2k(p, f, lane, nxt);
+  for (; f < f_end; f += W2K) {
+    v2f ze[8], zo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 w = win4[lane + 64 * j];   // L1/L2-resident (8 KB), re-read per frame instead of 32 VGPRs
+      ze[j] = (v2f){nxt[j].x * w.x, nxt[j].y * w.y};
+      zo[j] = (v2f){nxt[j].z * w.z, nxt[j].w * w.w};
+    }
+    if (f + W2K < f_end) load_frame2k(p, f + W2K, lane, nxt);
+    fft512<false>(ze, tw, lds, lane);
+    fft512<false>(zo, tw, lds, lane);
+    // radix-2: H = Z / 2 (the real split wants the half): H[k] = Ze/2 + (W1024^k / 2) Zo, H[k+512] = Ze/2 - ...
+    v2f z[16];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const v2f t = cmul_v(zo[m], tw.getr(m));
+      const v2f e = ze[m] * hh;
+      z[m] = e + t;
+      z[m + 8] = e - t;
+    }
+    v2f pm[16];
+    mirror1024(z, pm, lane);
+    // X[k] = (H[k] + conj H') - i W2048^k (H[k] - conj H'),  H = Z / 2,  H' = H[1024 - k]  (k = 0: H' = H[0], X[0] real)
+    const float2 nyq = make_float2(2.0f * (z[0].x - z[0].y), 0.0f);    // X[1024] = Re Z[0] - Im Z[0] (lane 0)
+    float2* row = p.X + f * F2K;
+    float* prow = WRITE_PHASE ? p.phase_out + f * F2K : nullptr;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const v2f e = add_conj(z[m], pm[m]);
+      const v2f d = sub_conj(z[m], pm[m]);
+      const v2f xk = add_mi(e, cmul_v(d, w2[64 * m]));      // e - i W d
+      row[lane + 64 * m] = to_f2(xk);
+      if (WRITE_PHASE) prow[lane + 64 * m] = fast_atan2f(xk.y, xk.x);
+    }
+    if (lane == 0) {
+      row[1024] = nyq;
+      if (WRITE_PHASE) prow[1024] = fast_atan2f(nyq.y, nyq.x);
+    }
+  }
+}
+
+__device__ __forceinline__ void sincos_big2k(float phase, float& s, float& c) {
+  double t = (double)phase * 0.15915494309189533577;  // 1 / (2 pi)
+  t -= rint(t);
+  const float r = (float)t;
+  s = __builtin_amdgcn_sinf(r);
+  c = __builtin_amdgcn_cosf(r);
+}
+
+// irfft(X) * window, frames out (the overlap-add is stft_generic.hip's gather): complex or polar input
+template <bool POLAR>
+__global__ __launch_bounds__(64 * W2K, 3) void irfft2048_frames_kernel(P2k p) {
+  __shared__ float2 lds_all[W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* tab = lds_all + W2K * kFftLdsFloat2PerWave;
+  const v2f* w2 = reinterpret_cast<const v2f*>(tab + kTwiddleCount) + lane;
+  stage_tables2k<true>(p, tab, tab + kTwiddleCount);
+  const LdsTwiddles<true> tw = {tab, lane};      // tw.getr(m) = W1024^(lane + 64 m)
+  const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
+  long long f_end = f_begin + p.frames_per_block;
+  if (f_end > p.total_frames) f_end = p.total_frames;
+  const float4* win4 = reinterpret_cast<const float4*>(p.window);
+  const float scale = 1.0f / 2048.0f;
+  for (long long f = f_begin + wave; f < f_end; f += W2K) {
+    v2f v[16];
+    float nyq_re;
+    if (POLAR) {
+      const float* mrow = p.mag + f * F2K;
+      const float* prow = p.phase + f * F2K;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        float sn, cs;
+        const float a = mrow[lane + 64 * m];
+        sincos_big2k(prow[lane + 64 * m], sn, cs);
+        v[m] = (v2f){a * cs, a * sn};
+      }
+      float sn, cs;
+      sincos_big2k(prow[1024], sn, cs);
+      nyq_re = mrow[1024] * cs;
+    } else {
+      const float2* row = p.X + f * F2K;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) v[m] = to_v(row[lane + 64 * m]);
+      nyq_re = row[1024].x;
+    }
+    if (lane == 0) v[0].y = 0.0f;                       // c2r ignores the imaginary parts of DC and Nyquist
+    v2f pm[16];
+    mirror1024(v, pm, lane);
+    if (lane == 0) pm[0] = (v2f){nyq_re, 0.0f};         // partner of k = 0 is X[1024]
+    // Z = E + i O,  E = X + conj X',  O = (X - conj X') conj(W2048^k)   (twice the true value: folded into `scale`)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const v2f e = add_conj(v[m], pm[m]);
+      const v2f d = cmul_conj_v(sub_conj(v[m], pm[m]), w2[64 * m]);
+      v[m] = add_pi(e, d);
+    }
+    // radix-2 backwards: even samples from Z[k] + Z[k+512], odd ones from (Z[k] - Z[k+512]) conj(W1024^k)
+    v2f ze[8], zo[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      ze[m] = v[m] + v[m + 8];
+      zo[m] = cmul_conj_v(v[m] - v[m + 8], tw.getr(m));
+    }
+    fft512<true>(ze, tw, lds, lane);
+    fft512<true>(zo, tw, lds, lane);
+    float4* dst = reinterpret_cast<float4*>(p.y + f * N2K);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 w = win4[lane + 64 * j];
+      dst[lane + 64 * j] = make_float4(ze[j].x * (w.x * scale), ze[j].y * (w.y * scale), zo[j].x * (w.z * scale),
+                                       zo[j].y * (w.w * scale));
+    }
+  }
+}
+
+static long long frames_per_block_2k(long long nframes) {
+  const long long max_blocks = 256LL * 8;
+  long long fpb = (nframes + max_blocks - 1) / max_blocks;
+  fpb = ((fpb + W2K - 1) / W2K) * W2K;
+  return fpb < W2K ? W2K : fpb;
+}
+
+int launch_stft2048_fwd(const float* x, long long B, long long L, long long clip_stride, long long T, int hop, int center,
+                        const float* window, const float2* tw, const float2* tw2k, float2* out, float* phase,
+                        hipStream_t stream) {
+  const long long nframes = B * T;
+  if (nframes == 0) return 0;
+  P2k p = {};
+  p.x = x; p.window = window; p.tw = tw; p.tw2k = tw2k; p.X = out; p.phase_out = phase;
+  p.L = L; p.clip_stride = clip_stride; p.T = T; p.total_frames = nframes; p.hop = hop; p.center = center;
+  p.frames_per_block = frames_per_block_2k(nframes);
+  const long long blocks = (nframes + p.frames_per_block - 1) / p.frames_per_block;
+  if (phase) hipLaunchKernelGGL(stft2048_fwd_kernel<true>, dim3((unsigned)blocks), dim3(64 * W2K), 0, stream, p);
+  else hipLaunchKernelGGL(stft2048_fwd_kernel<false>, dim3((unsigned)blocks), dim3(64 * W2K), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int launch_irfft2048_frames(const float2* X, const float* mag, const float* phase, long long nframes, const float* window,
+                            const float2* tw, const float2* tw2k, float* frames, hipStream_t stream) {
+  if (nframes == 0) return 0;
+  P2k p = {};
+  p.X = const_cast<float2*>(X); p.mag = mag; p.phase = phase; p.window = window; p.tw = tw; p.tw2k = tw2k; p.y = frames;
+  p.total_frames = nframes;
+  p.frames_per_block = frames_per_block_2k(nframes);
+  const long long blocks = (nframes + p.frames_per_block - 1) / p.frames_per_block;
+  if (X) hipLaunchKernelGGL(irfft2048_frames_kernel<false>, dim3((unsigned)blocks), dim3(64 * W2K), 0, stream, p);
+  else hipLaunchKernelGGL(irfft2048_frames_kernel<true>, dim3((unsigned)blocks), dim3(64 * W2K), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // namespace at_hip

@@ -352,3 +352,43 @@ def test_bench_step_at_full_batch_vs_oracle(dev):
     # and the stage-by-stage path produces the same spectrum bit for bit / the same features within the bar
     assert torch.equal(stft(x[1000:1008]), X[1000:1008])
     assert rel_max(cpu(mag(X[1000:1008])), cpu(feat[1000:1008])) < TOL
+
+
+@pytest.mark.parametrize("n", [512, 2048])
+def test_register_core_sizes_512_and_2048(dev, n):
+    """n_fft = 512 (two frames per wave-level FFT) and 2048 (two FFTs + a radix-2 stage per frame) on the register core:
+    forward, complex and polar inverse, phase side output, realtime frames, odd frame counts, unaligned clip
+    lengths and hops, STFT and DGT windows -- against the oracle."""
+    from acids_transforms_amd import ops
+    for (B, L, h) in [(3, 9 * n + 7, n // 4), (2, 5 * n + 1, 100), (1, n // 2 + 3, n // 4), (5, 4 * n, n // 2),
+                      (2, 7 * n + 2, n // 8), (1, 20 * n, n // 4)]:
+        g = torch.Generator().manual_seed(B * 131 + L + h)
+        x = torch.randn(B, L, generator=g)
+        for cls, w in [(A.STFT, O.hann_window(n)), (A.DGT, O.gauss_window(n))]:
+            iw = w if cls is A.STFT else O.dual_window(w, n, h)
+            m = cls(n_fft=n, hop_length=h).to(dev)
+            X = m(x.to(dev))
+            Xr = O.stft_forward(x, w, n, h)
+            assert X.shape == Xr.shape, (B, L, h)
+            assert rel_max(cpu(X), Xr.numpy()) < TOL, (cls.__name__, B, L, h)
+            if Xr.shape[-2] > 1 and n // h >= 2 and n % h == 0:
+                y = m.invert(X)
+                yr = O.istft(Xr, iw, n, h)
+                assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL, (cls.__name__, B, L, h)
+                yp = m._istft(mag=X.abs(), phase=X.angle())                 # polar input path
+                assert rel_max(cpu(yp), yr.numpy()) < 2e-5
+    # eager phase output, realtime (pre-framed) forward / inverse
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(2, 6 * n, generator=g)
+    st = A.STFT(n_fft=n, hop_length=n // 4).to(dev)
+    st.eager_phase = True
+    X = st(x.to(dev))
+    assert rel_max(cpu(st.phase_buffer), cpu(X.angle())) < 1e-5
+    rs = A.RealtimeSTFT(n_fft=n, hop_length=n // 4).to(dev)
+    fr = torch.randn(3, 5, n, generator=g)
+    Xf = rs(fr.to(dev))
+    Xfr = O.rt_forward(fr, O.hann_window(n))
+    assert rel_max(cpu(Xf), Xfr.numpy()) < TOL
+    assert rel_max(cpu(rs.invert(Xf)), O.rt_invert(Xfr, O.hann_window(n)).numpy()) < TOL
+    assert rel_max(cpu(ops.irfft_frames(None, rs.inv_window[:n], n, mag=Xf.abs(), phase=Xf.angle())),
+                   O.rt_invert(Xfr, O.hann_window(n)).numpy()) < 2e-5
