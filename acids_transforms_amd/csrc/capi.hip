@@ -31,11 +31,15 @@ int launch_stft2048_fwd(const float*, long long, long long, long long, long long
                         const float2*, float2*, float*, hipStream_t);
 int launch_irfft2048_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
                             const float2*, float*, hipStream_t);
+int launch_istft2048_ola(const float2*, const float*, const float*, long long, long long, int, const float*,
+                         const float*, const float2*, const float2*, float*, hipStream_t);
 // stft512.hip
 int launch_stft512_fwd(const float*, long long, long long, long long, long long, int, int, const float*, const float2*,
                        const float2*, float2*, float*, hipStream_t);
 int launch_irfft512_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
                            const float2*, float*, hipStream_t);
+int launch_istft512_ola(const float2*, const float*, const float*, long long, long long, int, const float*, const float*,
+                        const float2*, const float2*, float*, hipStream_t);
 
 constexpr int kMaxDevices = 16;
 static float2* g_twiddles[kMaxDevices] = {nullptr};
@@ -242,8 +246,15 @@ static bool istft_fast(int n_fft, int hop, const float* env16, const float* w) {
          (((uintptr_t)env16) & 7) == 0;
 }
 
+static bool istft2048_fused(int n_fft, int hop, const float* env, const float* w, const float* y) {
+  return n_fft == 2048 && (hop == 256 || hop == 512 || hop == 1024) && env != nullptr && (((uintptr_t)w) & 15) == 0 &&
+         (((uintptr_t)env) & 15) == 0 && (((uintptr_t)y) & 15) == 0;
+}
+
 size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop) {
   if (n_fft == 1024 && (hop == 128 || hop == 256 || hop == 512)) return 0;   // with the envelope table; see at_istft
+  if (n_fft == 2048 && (hop == 256 || hop == 512 || hop == 1024)) return 0;  // likewise (stft2048.hip)
+  if (n_fft == 512 && (hop == 64 || hop == 128 || hop == 256)) return 0;      // likewise (stft512.hip)
   return (size_t)B * (size_t)T * (size_t)n_fft * sizeof(float);
 }
 
@@ -260,6 +271,19 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
     const float2* tw = twiddles_for_current_device();
     if (!tw) return AT_ENOTINIT;
     return launch_istft1024_ola((const float2*)X_complex, mag, phase, B, T, hop, inv_window, env16, tw, y, s);
+  }
+  if (istft2048_fused(n_fft, hop, env16, inv_window, y)) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_istft2048_ola((const float2*)X_complex, mag, phase, B, T, hop, inv_window, env16, tw, tw2k, y, s);
+  }
+  if (n_fft == 512 && (hop == 64 || hop == 128 || hop == 256) && env16 && (((uintptr_t)inv_window) & 7) == 0 &&
+      (((uintptr_t)env16) & 7) == 0 && (((uintptr_t)y) & 7) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_istft512_ola((const float2*)X_complex, mag, phase, B, T, hop, inv_window, env16, tw, tw2k + 1024, y, s);
   }
   size_t need = (size_t)B * (size_t)T * (size_t)n_fft * sizeof(float);
   if (!workspace || workspace_bytes < need) return AT_EWORKSPACE;

@@ -243,6 +243,158 @@ __global__ __launch_bounds__(64 * W2K, 3) void irfft2048_frames_kernel(P2k p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// torch.istft for n_fft = 2048, hop = 256 / 512 / 1024 in one kernel: irfft + window + overlap-add + envelope
+// (reference stft.py:120-128, dgt.py:86-93; polar input: stft.py:157-161, dgt.py:152-154).
+// A wave walks consecutive frames of one clip.  A frame is 8 register slots of 256 samples (float4 per lane); a hop
+// is HS = hop / 256 slots, so the R = 8 / HS frames that overlap a hop are summed in registers: after frame t has
+// been added, block t of the padded signal (samples [t hop, (t + 1) hop)) is complete -- it is divided by the window
+// envelope of the frames that exist around it (the 2^R x hop table of at_istft_envelope_table) and stored once.
+// Output sample s is padded sample s + 1024 (center = True trims n_fft / 2 at both ends): block c is output hop
+// c - 1024 / hop.  A run of blocks [c0, c1) starts R - 1 frames early (warm-up) to have its first block complete.
+// ---------------------------------------------------------------------------
+struct P2kOla {
+  const float2* X;       // (B*T, 1025) complex64, or null
+  const float* mag;      // polar input
+  const float* phase;
+  const float* window;   // 2048 synthesis window samples
+  const float* env;      // 2^R x hop
+  const float2* tw;
+  const float2* tw2k;
+  float* y;              // (B, hop (T - 1))
+  long long B, T, runs_per_clip, blocks_per_run;
+};
+
+template <bool POLAR, int HS>
+__global__ __launch_bounds__(64 * W2K, 2) void istft2048_ola_kernel(P2kOla p) {
+  constexpr int HOP = 256 * HS, R = 8 / HS, LEAD = 1024 / HOP;      // LEAD: blocks trimmed at the front
+  __shared__ float2 lds_all[W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* tab = lds_all + W2K * kFftLdsFloat2PerWave;
+  const v2f* w2 = reinterpret_cast<const v2f*>(tab + kTwiddleCount) + lane;
+  for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * W2K) tab[i] = twiddle_for_lds<true>(p.tw, i);
+  for (int i = threadIdx.x; i < 1024; i += 64 * W2K) tab[kTwiddleCount + i] = p.tw2k[i];
+  __syncthreads();
+  const LdsTwiddles<true> tw = {tab, lane};
+  const long long run = (long long)blockIdx.x * W2K + wave;
+  const long long b = run / p.runs_per_clip;
+  if (b >= p.B) return;
+  const long long r = run - b * p.runs_per_clip;
+  const long long T = p.T;
+  // output hops q = 0 .. T - 2 are blocks c = q + LEAD
+  const long long c0 = LEAD + r * p.blocks_per_run;
+  long long c1 = c0 + p.blocks_per_run;
+  if (c1 > LEAD + T - 1) c1 = LEAD + T - 1;
+  if (c0 >= c1) return;
+  const float4* win4 = reinterpret_cast<const float4*>(p.window);
+  const float4* env4 = reinterpret_cast<const float4*>(p.env);
+  const float scale = 1.0f / 2048.0f;
+  float4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* yclip = p.y + b * (HOP * (T - 1));
+
+  for (long long t = c0 - (R - 1); t < c1; ++t) {
+    if (t >= 0 && t < T) {
+      const long long f = b * T + t;
+      v2f v[16];
+      float nyq_re;
+      if (POLAR) {
+        const float* mrow = p.mag + f * F2K;
+        const float* prow = p.phase + f * F2K;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          float sn, cs;
+          const float a = mrow[lane + 64 * m];
+          sincos_big2k(prow[lane + 64 * m], sn, cs);
+          v[m] = (v2f){a * cs, a * sn};
+        }
+        float sn, cs;
+        sincos_big2k(prow[1024], sn, cs);
+        nyq_re = mrow[1024] * cs;
+      } else {
+        const float2* row = p.X + f * F2K;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = to_v(row[lane + 64 * m]);
+        nyq_re = row[1024].x;
+      }
+      if (lane == 0) v[0].y = 0.0f;
+      v2f pm[16];
+      mirror1024(v, pm, lane);
+      if (lane == 0) pm[0] = (v2f){nyq_re, 0.0f};
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const v2f e = add_conj(v[m], pm[m]);
+        const v2f d = cmul_conj_v(sub_conj(v[m], pm[m]), w2[64 * m]);
+        v[m] = add_pi(e, d);
+      }
+      v2f ze[8], zo[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        ze[m] = v[m] + v[m + 8];
+        zo[m] = cmul_conj_v(v[m] - v[m + 8], tw.getr(m));
+      }
+      fft512<true>(ze, tw, lds, lane);
+      fft512<true>(zo, tw, lds, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 w = win4[lane + 64 * j];
+        acc[j].x += ze[j].x * (w.x * scale);
+        acc[j].y += ze[j].y * (w.y * scale);
+        acc[j].z += zo[j].x * (w.z * scale);
+        acc[j].w += zo[j].y * (w.w * scale);
+      }
+    }
+    // block t is complete: frames t - R + 1 .. t are all that cover it
+    if (t >= c0) {
+      int mask = 0;
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const long long ft = t - (R - 1) + q;          // bit q: oldest frame first (at_istft_envelope_table)
+        if (ft >= 0 && ft < T) mask |= 1 << q;
+      }
+      float* dst = yclip + (t - LEAD) * HOP;
+#pragma unroll
+      for (int j = 0; j < HS; ++j) {
+        const float4 e = env4[(size_t)mask * (HOP / 4) + lane + 64 * j];
+        *reinterpret_cast<float4*>(dst + 4 * (lane + 64 * j)) =
+            make_float4(acc[j].x / e.x, acc[j].y / e.y, acc[j].z / e.z, acc[j].w / e.w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8 - HS; ++j) acc[j] = acc[j + HS];
+#pragma unroll
+    for (int j = 8 - HS; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+int launch_istft2048_ola(const float2* X, const float* mag, const float* phase, long long B, long long T, int hop,
+                         const float* window, const float* env, const float2* tw, const float2* tw2k, float* y,
+                         hipStream_t stream) {
+  if (B == 0 || T <= 1) return 0;
+  P2kOla p = {X, mag, phase, window, env, tw, tw2k, y, B, T, 0, 0};
+  const long long blocks = T - 1;                        // output hops per clip
+  // runs long enough that the R - 1 warm-up frames stay a small share, short enough to fill the chip
+  long long runs = (B >= 2048) ? 1 : (2048 + B - 1) / B;
+  long long per = (blocks + runs - 1) / runs;
+  const long long min_per = 24;
+  if (per < min_per) per = min_per < blocks ? min_per : blocks;
+  runs = (blocks + per - 1) / per;
+  p.runs_per_clip = runs;
+  p.blocks_per_run = per;
+  const long long waves = B * runs;
+  const unsigned grid = (unsigned)((waves + W2K - 1) / W2K);
+#define OLA2K(POLAR_, HS_) hipLaunchKernelGGL((istft2048_ola_kernel<POLAR_, HS_>), dim3(grid), dim3(64 * W2K), 0, stream, p)
+  const bool polar = (X == nullptr);
+  if (hop == 256) { if (polar) OLA2K(true, 1); else OLA2K(false, 1); }
+  else if (hop == 512) { if (polar) OLA2K(true, 2); else OLA2K(false, 2); }
+  else if (hop == 1024) { if (polar) OLA2K(true, 4); else OLA2K(false, 4); }
+  else return -2;
+#undef OLA2K
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 static long long frames_per_block_2k(long long nframes) {
   const long long max_blocks = 256LL * 8;
   long long fpb = (nframes + max_blocks - 1) / max_blocks;

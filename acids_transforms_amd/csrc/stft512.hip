@@ -177,8 +177,9 @@ __device__ __forceinline__ void sincos_big5(float phase, float& s, float& c) {
 
 // one frame's one-sided spectrum -> A[k] * 2 (k = lane + 64 m, m = 0..3): E + i O of the inverse split
 template <bool POLAR>
-__device__ __forceinline__ void load_split5(const P5& p, long long f, int lane, const v2f (&w5)[4], v2f (&a)[4]) {
-  if (f >= p.total_frames) {
+__device__ __forceinline__ void load_split5(const P5& p, long long f, bool exists, int lane, const v2f (&w5)[4],
+                                            v2f (&a)[4]) {
+  if (!exists) {              // wave-uniform: a missing frame contributes a zero spectrum
 #pragma unroll
     for (int m = 0; m < 4; ++m) a[m] = (v2f){0.f, 0.f};
     return;
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(64 * W5) void irfft512_frames_kernel(P5 p) {
   if (pr_end > n_pairs) pr_end = n_pairs;
   for (long long pr = pr_begin + wave; pr < pr_end; pr += W5) {
     v2f a[4], b[4];
-    load_split5<POLAR>(p, 2 * pr, lane, w5, a);
-    load_split5<POLAR>(p, 2 * pr + 1, lane, w5, b);
+    load_split5<POLAR>(p, 2 * pr, 2 * pr < p.total_frames, lane, w5, a);
+    load_split5<POLAR>(p, 2 * pr + 1, 2 * pr + 1 < p.total_frames, lane, w5, b);
     // Y[k] = A + W512^k B, Y[k+256] = A - W512^k B
     v2f y[8];
 #pragma unroll
@@ -259,6 +260,159 @@ __global__ __launch_bounds__(64 * W5) void irfft512_frames_kernel(P5 p) {
       for (int j = 0; j < 8; ++j) dst[(lane >> 1) + 32 * j] = make_float2(y[j].x * win[j].x, y[j].y * win[j].y);
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// torch.istft for n_fft = 512, hop = 64 / 128 / 256 in one kernel: irfft + window + overlap-add + envelope
+// (reference stft.py:120-128, dgt.py:86-93; polar input stft.py:157-161, dgt.py:152-154).
+// A wave walks consecutive frame PAIRS (t, t + 1) of one clip; even lanes hold frame t, odd lanes frame t + 1, the
+// same complex sample index (lane >> 1) + 32 j in register slot j (a slot = 64 samples, a hop = HS slots).  Every lane
+// overlap-adds the frames of ITS parity in registers (they are two hops apart: the window slides 2 HS slots per pair
+// and the HS slots behind the first hop are kept as `carry` when they slide out).  With the pair's frames added,
+//   block t     = even[0 .. HS)      + odd.carry      (odd frames t - 1, t - 3, ... : their second hop)
+//   block t + 1 = even[HS .. 2 HS)   + odd[0 .. HS)
+// are complete: one DPP exchange with the neighbouring lane adds the two parities, the sum is divided by the window
+// envelope of the frames that exist around the block (2^R x hop table of at_istft_envelope_table) and stored once.
+// Output sample s is padded sample s + 256: block c is output hop c - 256 / hop.
+// ---------------------------------------------------------------------------
+struct P5Ola {
+  const float2* X;
+  const float* mag;
+  const float* phase;
+  const float* window;
+  const float* env;      // 2^R x hop
+  const float2* tw;
+  const float2* tw512;
+  float* y;              // (B, hop (T - 1))
+  long long B, T, runs_per_clip, pairs_per_run;
+};
+
+__device__ __forceinline__ v2f dpp_xor1_v2(v2f a) {
+  v2f r;
+  r.x = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(a.x), 0xB1, 0xF, 0xF, true));
+  r.y = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(a.y), 0xB1, 0xF, 0xF, true));
+  return r;
+}
+
+template <bool POLAR, int HS>
+__global__ __launch_bounds__(64 * W5) void istft512_ola_kernel(P5Ola p) {
+  constexpr int HOP = 64 * HS, R = 8 / HS, LEAD = 256 / HOP;
+  __shared__ float2 lds_all[W5 * kFftLdsFloat2PerWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int par = lane & 1, u = lane >> 1;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  Twiddles tw;
+  load_twiddles<true>(tw, p.tw, lane);
+  v2f w5[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) w5[m] = to_v(p.tw512[lane + 64 * m]);
+  const float scale = 1.0f / 1024.0f;
+  float2 win[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float2 w = reinterpret_cast<const float2*>(p.window)[u + 32 * j];
+    win[j] = make_float2(w.x * scale, w.y * scale);
+  }
+  const long long run = (long long)blockIdx.x * W5 + wave;
+  const long long b = run / p.runs_per_clip;
+  if (b >= p.B) return;
+  const long long r = run - b * p.runs_per_clip;
+  const long long T = p.T;
+  // output hops q = 0 .. T - 2 are blocks c = q + LEAD; pair i holds frames 2 i, 2 i + 1 and completes blocks 2 i, 2 i + 1
+  const long long c_lo = LEAD, c_hi = LEAD + T - 1;                       // valid blocks [c_lo, c_hi)
+  const long long i0 = c_lo / 2 + r * p.pairs_per_run;
+  long long i1 = i0 + p.pairs_per_run;
+  const long long i_end = (c_hi + 1) / 2;                                  // first pair with no valid block
+  if (i1 > i_end) i1 = i_end;
+  if (i0 >= i1) return;
+  // P5 view for the shared spectrum loader
+  P5 q5 = {};
+  q5.X = const_cast<float2*>(p.X); q5.mag = p.mag; q5.phase = p.phase;
+  const float2* env2 = reinterpret_cast<const float2*>(p.env);
+  float* yclip = p.y + b * (HOP * (T - 1));
+  v2f acc[8], carry[HS];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = (v2f){0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < HS; ++j) carry[j] = (v2f){0.f, 0.f};
+
+  constexpr int WARM = (R + 1) / 2;                                       // pairs that start early: R - 1 frames back
+  for (long long i = i0 - WARM; i < i1; ++i) {
+    // slide this lane's window two hops; what leaves behind the first hop is the carry
+#pragma unroll
+    for (int j = 0; j < HS; ++j) carry[j] = (HS + j < 8) ? acc[HS + j] : (v2f){0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (j + 2 * HS < 8) ? acc[j + 2 * HS] : (v2f){0.f, 0.f};
+    const long long ta = 2 * i, tb = 2 * i + 1;
+    if (tb >= 0 && ta < T) {                     // at least one frame of the pair exists (wave-uniform)
+      v2f a[4], bb[4];                           // frames outside [0, T) of THIS clip read as zero spectra
+      load_split5<POLAR>(q5, b * T + ta, ta >= 0 && ta < T, lane, w5, a);
+      load_split5<POLAR>(q5, b * T + tb, tb >= 0 && tb < T, lane, w5, bb);
+      v2f y[8];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const v2f t = cmul_v(bb[m], w5[m]);
+        y[m] = a[m] + t;
+        y[m + 4] = a[m] - t;
+      }
+      fft512<true>(y, tw, lds, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (v2f){y[j].x * win[j].x, y[j].y * win[j].y};
+    }
+    if (i < i0) continue;
+    // the two blocks this pair completes
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const long long c = 2 * i + half;
+      int mask = 0;
+#pragma unroll
+      for (int qq = 0; qq < R; ++qq) {
+        const long long ft = c - (R - 1) + qq;
+        if (ft >= 0 && ft < T) mask |= 1 << qq;
+      }
+      const bool valid = c >= c_lo && c < c_hi;
+      float2* dst = reinterpret_cast<float2*>(yclip + (c - LEAD) * HOP);
+#pragma unroll
+      for (int j = 0; j < HS; ++j) {
+        // this lane's parity share of slot j of the block, then the neighbour's
+        const v2f mine = (half == 0) ? (par ? carry[j] : acc[j]) : (par ? acc[j] : acc[HS + j]);
+        const v2f sum = mine + dpp_xor1_v2(mine);
+        // a lane pair holds the same sum: even lanes store the first half of the slot pair range, odd lanes ... both
+        // lanes of a pair would write the same 8 bytes, so the even lane alone stores
+        if (valid && par == 0) {
+          const float2 e = env2[(size_t)mask * (HOP / 2) + u + 32 * j];
+          dst[u + 32 * j] = make_float2(sum.x / e.x, sum.y / e.y);
+        }
+      }
+    }
+  }
+}
+
+int launch_istft512_ola(const float2* X, const float* mag, const float* phase, long long B, long long T, int hop,
+                        const float* window, const float* env, const float2* tw, const float2* tw512, float* y,
+                        hipStream_t stream) {
+  if (B == 0 || T <= 1) return 0;
+  P5Ola p = {X, mag, phase, window, env, tw, tw512, y, B, T, 0, 0};
+  const long long lead = 256 / hop;
+  const long long pairs = (lead + T - 1 + 1) / 2 - lead / 2;             // pairs that hold a valid block
+  long long runs = (B >= 4096) ? 1 : (4096 + B - 1) / B;
+  long long per = (pairs + runs - 1) / runs;
+  const long long min_per = 16;
+  if (per < min_per) per = min_per < pairs ? min_per : pairs;
+  if (per < 1) per = 1;
+  runs = (pairs + per - 1) / per;
+  p.runs_per_clip = runs;
+  p.pairs_per_run = per;
+  const long long waves = B * runs;
+  const unsigned grid = (unsigned)((waves + W5 - 1) / W5);
+#define OLA5(POLAR_, HS_) hipLaunchKernelGGL((istft512_ola_kernel<POLAR_, HS_>), dim3(grid), dim3(64 * W5), 0, stream, p)
+  const bool polar = (X == nullptr);
+  if (hop == 64) { if (polar) OLA5(true, 1); else OLA5(false, 1); }
+  else if (hop == 128) { if (polar) OLA5(true, 2); else OLA5(false, 2); }
+  else if (hop == 256) { if (polar) OLA5(true, 4); else OLA5(false, 4); }
+  else return -2;
+#undef OLA5
+  return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 static long long pairs_per_block_5(long long npairs) {

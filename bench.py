@@ -631,6 +631,22 @@ def main():
             del Xh
         return res
 
+    def extra_other_sizes():
+        # n_fft 512 / 2048 (hop n_fft / 4) on the register FFT core: two frames per wave FFT / two FFTs per frame
+        res = {}
+        for n in (512, 2048):
+            st = A.STFT(sr=SR, n_fft=n, hop_length=n // 4).to(dev)
+            Xh = st(x)
+            f_ms = timed_ms(lambda: st(x), 3, 1)
+            i_ms = timed_ms(lambda: st.invert(Xh), 3, 1)
+            frames = B * Xh.shape[-2]
+            bytes_per_frame = (n // 4) * 4 + (n // 2 + 1) * 8
+            res["n_fft_%d" % n] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(f_ms, 4), "inverse_ms": round(i_ms, 4),
+                                   "forward_frac_of_8TBps": round(frames * bytes_per_frame / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "inverse_frac_of_8TBps": round(frames * bytes_per_frame / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del Xh
+        return res
+
     def extra_griffin_lim():
         m = stft(x).abs()
         stft.invert(m)
@@ -647,6 +663,7 @@ def main():
             guarded("hbm_probe", extra_hbm_probe)
             guarded("h2d_inclusive", extra_h2d_inclusive)
             guarded("other_hops", extra_other_hops)
+            guarded("other_sizes", extra_other_sizes)
             guarded("griffin_lim_invert", extra_griffin_lim)
             guarded("phase_representations", extra_phase_repr)
         guarded("config4", lambda: config4_figures(max(10, args.steps // 5), 3))     # all ranks: it holds collectives

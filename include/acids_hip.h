@@ -100,8 +100,10 @@ size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop);
  *     replaces stft.py:120-128, dgt.py:86-93 (complex input: X != NULL), and
  *     `x * exp(1j*phase)` + istft, stft.py:157-161 / dgt.py:152-154
  *     (polar input: X == NULL, mag and phase given).
- * y: (B, hop*(T-1)).  env16 (at_istft_envelope_table) is required for n_fft=1024 with hop=128, 256 or 512 -- the
- * fused kernel, for which at_istft_workspace_bytes is 0 -- and may be NULL otherwise. */
+ * y: (B, hop*(T-1)).  env16 (at_istft_envelope_table) is required for n_fft=1024 with hop=128, 256 or 512 and for
+ * n_fft=2048 / 512 with hop = n_fft/8, n_fft/4 or n_fft/2 -- the fused kernels, for which at_istft_workspace_bytes
+ * is 0 -- and may be NULL otherwise.  n_fft = 512 and 2048 run on the register FFT core (stft512.hip, stft2048.hip), the other sizes on
+ * the generic LDS kernel. */
 int at_istft(const float *X_complex, const float *mag, const float *phase, int64_t B, int64_t T, int n_fft, int hop,
              const float *inv_window, const float *env16, float *y, void *workspace, size_t workspace_bytes,
              void *stream);
