@@ -60,6 +60,8 @@ _SIGNATURES = {
     "at_pghi_rt_workspace_bytes": [c_int, c_int, c_int],
     "at_pghi_realtime": [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_flt, c_int, c_int, c_flt, c_flt, c_f, c_f, c_f,
                          c_f, c_sz, c_f],
+    "at_pghi_realtime_seeded": [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_flt, c_int, c_int, c_flt, c_flt, c_f, c_f, c_sz,
+                                c_f],
     "at_rt_update_buffers": [c_f, c_f, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_griffinlim_update": [c_f, c_f, c_f, c_flt, c_i64, c_f, c_f],
     "at_istft_griffinlim": [c_f, c_f, c_f, c_flt, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f],

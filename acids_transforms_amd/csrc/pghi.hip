@@ -997,7 +997,9 @@ struct RtParams {
   const float* mag_hist;    // (S, 2, F)
   const float* mag;         // (S, n, F)
   const float* prev_phase;  // (S, F)
-  const float* noise;       // (S, n, F)
+  const float* noise;       // (S, n, F): caller's draws, or the workspace array the gradient kernel fills (seeded mode)
+  float* noise_gen;         // seeded mode: where the gradient kernel writes its draws (== noise), else null
+  unsigned* rng_state;      // seeded mode: {seed lo, seed hi, step counter, unused}; the heap kernel bumps the counter
   float* phase_out;         // (S, n, F)
   float* spec;              // (S, R, F) work
   float* hist;              // (S, R, F) work (untouched copy)
@@ -1013,6 +1015,30 @@ struct RtParams {
 __device__ __forceinline__ float rt_mag(const RtParams& p, int s, int j, int k) {
   const float v = (j < 2) ? p.mag_hist[((long long)s * 2 + j) * p.F + k] : p.mag[((long long)s * p.n + (j - 2)) * p.F + k];
   return fmaxf(v, p.eps);
+}
+
+// Standard-normal draws for the bins at or below the tolerance (dgt.py:404-405: torch.randn_like), generated on the
+// device so that a captured streaming step needs no generator launch: Philox-4x32-10 keyed by the session's seed, counter
+// = (element index, step counter), Box-Muller on two of the four outputs.  Statistical parity only (the reference's
+// draws are torch's; tests/test_stream_quant_gpu.py checks mean / variance / tails / step-to-step independence).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float philox_normal(unsigned long long index, unsigned step, const unsigned* state) {
+  unsigned r[4];
+  philox4x32_10((unsigned)index, (unsigned)(index >> 32), step, 0x5eedu, state[0], state[1], r);
+  const float u1 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);    // (0, 1]
+  const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);             // [0, 1)
+  return sqrtf(-2.0f * logf(u1)) * __builtin_amdgcn_cosf(u2);             // v_cos_f32 takes revolutions
 }
 
 __global__ __launch_bounds__(256) void pghi_grad_rt_kernel(RtParams p) {
@@ -1038,11 +1064,15 @@ __global__ __launch_bounds__(256) void pghi_grad_rt_kernel(RtParams p) {
     p.tgradw[i] = (-fmul) * dxdt + pi_f;                               // :396
     p.spec[i] = c;
     p.hist[i] = c;
+    if (p.noise_gen && j >= 2)      // one draw per new bin (rows 2 .. n + 1), same indexing as a caller-supplied array
+      p.noise_gen[(long long)s * p.n * p.F + (long long)(j - 2) * p.F + k] =
+          philox_normal((unsigned long long)s * p.n * p.F + (unsigned long long)(j - 2) * p.F + k, p.rng_state[2], p.rng_state);
   }
 }
 
 // dgt.py:399-466, one wave per stream
 __global__ __launch_bounds__(64) void pghi_hgi_rt_kernel(RtParams p) {
+  if (p.rng_state && blockIdx.x == 0 && threadIdx.x == 0) p.rng_state[2] += 1u;   // next step draws from a new counter (the gradient kernel has finished)
   const int s = blockIdx.x;
   if (s >= p.S) return;
   const int lane = threadIdx.x;
@@ -1153,6 +1183,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_kernel(RtParams p) {
 // Same algorithm with the per-frame state in LDS: a frame's heap holds at most ~2F entries and touches only
 // two rows of each array, so the whole frame step runs out of the CU's LDS (one wave per stream, F <= 1025).
 __global__ __launch_bounds__(64) void pghi_hgi_rt_lds_kernel(RtParams p) {
+  if (p.rng_state && blockIdx.x == 0 && threadIdx.x == 0) p.rng_state[2] += 1u;   // next step draws from a new counter (the gradient kernel has finished)
   extern __shared__ __attribute__((aligned(16))) float rt_smem[];
   const int s = blockIdx.x;
   if (s >= p.S) return;
@@ -1274,6 +1305,7 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_lds_kernel(RtParams p) {
 // LDS round trips down and a few up per pop (~3600 cycles); the cooperative pop resolves five levels per round
 // with one wide LDS gather.  Same binary heap, same sift rules, same pop order.
 __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
+  if (p.rng_state && blockIdx.x == 0 && threadIdx.x == 0) p.rng_state[2] += 1u;   // next step draws from a new counter (the gradient kernel has finished)
   extern __shared__ __attribute__((aligned(16))) float rt_smem_all[];
   // one wave per stream, 1 to 4 independent waves per workgroup (see pghi_hgi_offline_coop_kernel)
   const int wave = threadIdx.x >> 6;
@@ -1582,25 +1614,31 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
 
 size_t at_pghi_rt_workspace_bytes(int S, int n, int F) {
   const size_t per = (size_t)(n + 2) * (size_t)F;
-  return (size_t)S * (5 * per * sizeof(float) + (4 * (size_t)F + 8) * sizeof(HeapItem)) + 256;
+  // spec, hist, tgradw, fgradw, phase (n + 2 rows each) + device-drawn noise (n rows) + heap
+  return (size_t)S * (6 * per * sizeof(float) + (4 * (size_t)F + 8) * sizeof(HeapItem)) + 256;
 }
 
-int at_pghi_realtime(const float* mag_hist, const float* mag, const float* prev_phase, const float* noise, int S, int n,
-                     int F, float gamma, int n_fft, int hop, float tol, float eps, float* phase, float* tgradw_or_null,
-                     float* fgradw_or_null, void* workspace, size_t workspace_bytes, void* stream) {
+static int pghi_realtime_impl(const float* mag_hist, const float* mag, const float* prev_phase, const float* noise,
+                              unsigned* rng_state, int S, int n, int F, float gamma, int n_fft, int hop, float tol, float eps,
+                              float* phase, float* tgradw_or_null, float* fgradw_or_null, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   if (S < 0 || n <= 0 || F <= 0 || n_fft <= 0 || hop <= 0) return AT_EINVAL;
   if (S == 0) return AT_OK;
-  if (!mag_hist || !mag || !prev_phase || !noise || !phase) return AT_EINVAL;
+  if (!mag_hist || !mag || !prev_phase || !phase) return AT_EINVAL;
+  if ((noise == nullptr) == (rng_state == nullptr)) return AT_EINVAL;     // exactly one source of draws
   if (!workspace || workspace_bytes < at_pghi_rt_workspace_bytes(S, n, F)) return AT_EWORKSPACE;
   const size_t per = (size_t)(n + 2) * (size_t)F;
   float* w = (float*)workspace;
   RtParams p;
-  p.mag_hist = mag_hist; p.mag = mag; p.prev_phase = prev_phase; p.noise = noise; p.phase_out = phase;
+  p.mag_hist = mag_hist; p.mag = mag; p.prev_phase = prev_phase; p.phase_out = phase;
+  p.noise_gen = noise ? nullptr : w + 5 * (size_t)S * per;
+  p.noise = noise ? noise : p.noise_gen;
+  p.rng_state = rng_state;
   p.spec = w; p.hist = w + (size_t)S * per;
   p.tgradw = tgradw_or_null ? tgradw_or_null : w + 2 * (size_t)S * per;
   p.fgradw = fgradw_or_null ? fgradw_or_null : w + 3 * (size_t)S * per;
   p.phase = w + 4 * (size_t)S * per;
-  uintptr_t hp = ((uintptr_t)(w + 5 * (size_t)S * per) + 15) & ~(uintptr_t)15;
+  uintptr_t hp = ((uintptr_t)(w + 6 * (size_t)S * per) + 15) & ~(uintptr_t)15;
   p.heap = (HeapItem*)hp;
   p.S = S; p.n = n; p.F = F; p.n_fft = n_fft; p.hop = hop; p.gamma = gamma; p.tol = tol; p.eps = eps;
   hipStream_t s = (hipStream_t)stream;
@@ -1628,6 +1666,22 @@ int at_pghi_realtime(const float* mag_hist, const float* mag, const float* prev_
   else
     hipLaunchKernelGGL(pghi_hgi_rt_kernel, dim3((unsigned)S), dim3(64), 0, s, p);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+int at_pghi_realtime(const float* mag_hist, const float* mag, const float* prev_phase, const float* noise, int S, int n,
+                     int F, float gamma, int n_fft, int hop, float tol, float eps, float* phase, float* tgradw_or_null,
+                     float* fgradw_or_null, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!noise) return AT_EINVAL;
+  return pghi_realtime_impl(mag_hist, mag, prev_phase, noise, nullptr, S, n, F, gamma, n_fft, hop, tol, eps, phase,
+                            tgradw_or_null, fgradw_or_null, workspace, workspace_bytes, stream);
+}
+
+int at_pghi_realtime_seeded(const float* mag_hist, const float* mag, const float* prev_phase, uint32_t* rng_state, int S, int n,
+                            int F, float gamma, int n_fft, int hop, float tol, float eps, float* phase, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!rng_state) return AT_EINVAL;
+  return pghi_realtime_impl(mag_hist, mag, prev_phase, nullptr, rng_state, S, n, F, gamma, n_fft, hop, tol, eps, phase, nullptr,
+                            nullptr, workspace, workspace_bytes, stream);
 }
 
 int at_rt_update_buffers(const float* mag, const float* phase, int S, int n, int F, const float* hist_in,

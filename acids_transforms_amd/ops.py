@@ -348,6 +348,21 @@ def pghi_realtime(mag_hist, mag, prev_phase, noise, gamma, n_fft, hop, tol, eps=
     return (phase, tg, fg) if debug else phase
 
 
+def pghi_realtime_seeded(mag_hist, mag, prev_phase, rng_state, gamma, n_fft, hop, tol, eps=1.1920929e-07):
+    """pghi_realtime with the below-tolerance draws made on the device (Philox keyed by `rng_state`, a 4-element int32
+    tensor {seed lo, seed hi, step counter, 0} that the call advances): nothing but the kernels in a captured step."""
+    require_device(mag, mag_hist, prev_phase, rng_state)
+    mag_hist, mag, prev_phase = _f32c(mag_hist), _f32c(mag), _f32c(prev_phase)
+    assert rng_state.dtype == torch.int32 and rng_state.numel() == 4 and rng_state.is_contiguous()
+    S, n, F = mag.shape
+    phase = torch.empty_like(mag)
+    wsb = lib().at_pghi_rt_workspace_bytes(S, n, F)
+    ws = _workspace(wsb, mag.device)
+    check(lib().at_pghi_realtime_seeded(ptr(mag_hist), ptr(mag), ptr(prev_phase), ptr(rng_state), S, n, F, gamma, n_fft, hop,
+                                        tol, eps, ptr(phase), ptr(ws), wsb, stream_ptr()), "at_pghi_realtime_seeded")
+    return phase
+
+
 def rt_update_buffers_(mag, phase, mag_hist, prev_phase):
     """RealtimeDGT.update_buffers (dgt.py:330-336) IN PLACE on the state tensors mag_hist (S, 2, F) and
     prev_phase (S, F), for x = mag * exp(i * phase) with mag / phase (S, n, F)."""

@@ -38,7 +38,7 @@ class StreamingDGTSession:
         """streams: concurrent streams S; chunk: samples per step, a whole number of hops (>= 1 hop).
         `magnitude_fn`, if given, maps the (S, n, F) magnitudes to the magnitudes to resynthesise (a model
         working on |X|); it must be capturable (device ops only).  random_phase_below_tolerance: True = standard-normal
-        phases for the bins at or below the tolerance (dgt.py:404-405), drawn inside the step; False = zeros;
+        phases for the bins at or below the tolerance (dgt.py:404-405), drawn inside the RTPGHI kernels; False = zeros;
         "external" = read from the persistent buffer `noise_in` (S, n, F), which the caller fills before each step
         (parity tests feed the reference's recorded draws).  mel_bands > 0 also emits log1p mel features of
         every analysed frame (`mel_out`, (S, n, mel_bands)); mel_dtype "bf16" = the dense bf16 MFMA projection
@@ -69,6 +69,12 @@ class StreamingDGTSession:
         self.y_out = torch.zeros(self.S, self.C, device=dev)
         self.mag_out = torch.zeros(self.S, self.n, F, device=dev)
         self.noise_in = torch.zeros(self.S, self.n, F, device=dev) if self.random_phase == "external" else None
+        # True: draws made inside the RTPGHI kernels (Philox; seed taken from torch's generator, so torch.manual_seed
+        # governs it), counter advanced by the step itself -- no generator launch in the captured step
+        self.rng_state = None
+        if self.random_phase is True:
+            seed = torch.randint(-2 ** 31, 2 ** 31 - 1, (2,), dtype=torch.int64)
+            self.rng_state = torch.tensor([int(seed[0]), int(seed[1]), 0, 0], dtype=torch.int32, device=dev)
         self.mel_out = None
         if mel_bands:
             from .transforms.spectral_repr import Magnitude
@@ -108,19 +114,24 @@ class StreamingDGTSession:
                                 out=self.mel_out)
         if self.magnitude_fn is not None:
             mag = self.magnitude_fn(mag)
-        if self.random_phase == "external":
-            noise = self.noise_in
+        if self.rng_state is not None:
+            phase = ops.pghi_realtime_seeded(self.mag_hist, mag, self.prev_phase, self.rng_state, self._gamma, n_fft, h,
+                                             self._tol, self._eps)
         else:
-            noise = torch.randn_like(mag) if self.random_phase else torch.zeros_like(mag)
-        phase = ops.pghi_realtime(self.mag_hist, mag, self.prev_phase, noise, self._gamma, n_fft, h, self._tol, self._eps)
+            noise = self.noise_in if self.random_phase == "external" else torch.zeros_like(mag)
+            phase = ops.pghi_realtime(self.mag_hist, mag, self.prev_phase, noise, self._gamma, n_fft, h, self._tol,
+                                      self._eps)
         frames = ops.irfft_frames(None, self.dgt.inv_window[:n_fft], n_fft, mag=mag, phase=phase)
         ops.rt_update_buffers_(mag, phase, self.mag_hist, self.prev_phase)      # PGHI history, in place
         ops.oadd_invert(frames, self.tail, n_fft, h, self.keep, self.gain, out=self.y_out, in_place=True)
 
-    def step(self, chunk: torch.Tensor) -> torch.Tensor:
+    def step(self, chunk: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One chunk (S, C) in, one resynthesised chunk (S, C) out (delayed by n_fft - hop samples).  The returned
-        tensor (and `mag_out` / `mel_out`) is a persistent buffer, overwritten by the next step."""
-        self.x_in.copy_(chunk, non_blocking=True)
+        tensor (and `mag_out` / `mel_out`) is a persistent buffer, overwritten by the next step.  chunk=None: the
+        caller has written the samples into `x_in` itself (a producer kernel on the same stream): the step is then the
+        graph replay alone."""
+        if chunk is not None:
+            self.x_in.copy_(chunk, non_blocking=True)
         if self.graph is not None:
             self.graph.replay()
         else:

@@ -191,6 +191,14 @@ int at_pghi_realtime(const float *mag_hist, const float *mag, const float *prev_
                      float *tgradw_or_null, float *fgradw_or_null, void *workspace, size_t workspace_bytes,
                      void *stream);
 
+/* The same with the standard-normal draws of dgt.py:404-405 (torch.randn_like) made on the device, so that a captured
+ * streaming step needs no generator launch: Philox-4x32-10 keyed by rng_state[0..1] (seed), counter = (bin index,
+ * rng_state[2]); the call advances rng_state[2] by one.  rng_state: 4 x uint32 in device memory, owned by the caller
+ * (one per session).  Statistical parity only: the draws are not torch's. */
+int at_pghi_realtime_seeded(const float *mag_hist, const float *mag, const float *prev_phase, uint32_t *rng_state, int S,
+                            int n, int F, float gamma, int n_fft, int hop, float tol, float eps, float *phase,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 /* RealtimeDGT.update_buffers (dgt.py:330-336) for x = mag*exp(i*phase):
  * hist_out = |x[-2:]| (or [hist_in[1], |x[-1]|] when n == 1), phase_out = angle(x[-1]).  hist_out may alias hist_in
  * (every bin reads its history before it writes it). */

@@ -207,3 +207,39 @@ def test_offline_many_reseeds_exact_order(dev, kind):
         seeds = int(((r["phase"] == 0) & (m[b] >= 1e-2 * m[b].max())).sum())
         assert seeds > 20, seeds                                   # the case does reseed many times
         assert np.all(np.abs(cpu(ph[b]) - r["phase"]) <= phase_tol(r["phase"]))
+
+
+def test_realtime_seeded_draws_are_standard_normal(dev):
+    """at_pghi_realtime_seeded: the phases of the bins at or below the tolerance are standard-normal draws made on the
+    device (dgt.py:404-405 draws them with torch.randn_like: statistical parity) -- mean, variance, kurtosis, tails;
+    a new counter every call; same state, same draws."""
+    S, n, F = 64, 4, 513
+    mag = torch.full((S, n, F), 1e-6, device=dev)
+    mag[:, :, 100] = 1.0                                   # tolerance 1e-2: every other bin is below it
+    hist = torch.full((S, 2, F), 1e-6, device=dev)
+    prev = torch.zeros(S, F, device=dev)
+    d = A.RealtimeDGT(batch_size=[S]).to(dev)
+    args = (float(d.gamma), 1024, 256, float(d.tolerance), float(d.eps))
+    st = torch.tensor([12345, -6789, 0, 0], dtype=torch.int32, device=dev)
+    a = ops.pghi_realtime_seeded(hist, mag, prev, st, *args)
+    assert int(st[2]) == 1
+    b = ops.pghi_realtime_seeded(hist, mag, prev, st, *args)
+    assert int(st[2]) == 2
+    keep = torch.ones(F, dtype=torch.bool, device=dev)
+    keep[100] = False
+    xa, xb = a[:, :, keep].flatten().double(), b[:, :, keep].flatten().double()
+    N = xa.numel()
+    assert N == S * n * 512
+    for x in (xa, xb):
+        assert abs(float(x.mean())) < 6 / N ** 0.5
+        assert abs(float(x.var()) - 1.0) < 0.02
+        assert abs(float((x ** 4).mean()) - 3.0) < 0.15
+        assert float(x.abs().max()) < 6.0 and float((x.abs() > 3).double().mean()) < 0.005
+    assert abs(float((xa * xb).mean())) < 6 / N ** 0.5      # consecutive steps are uncorrelated
+    st2 = torch.tensor([12345, -6789, 0, 0], dtype=torch.int32, device=dev)
+    assert torch.equal(ops.pghi_realtime_seeded(hist, mag, prev, st2, *args), a)        # same state, same draws
+    st3 = torch.tensor([1, 2, 0, 0], dtype=torch.int32, device=dev)
+    assert not torch.equal(ops.pghi_realtime_seeded(hist, mag, prev, st3, *args), a)    # another seed, other draws
+    # with explicit noise the two entry points agree bit for bit on everything above the tolerance
+    ref = ops.pghi_realtime(hist, mag, prev, torch.zeros_like(mag), *args)
+    assert torch.equal(ref[:, :, 100], a[:, :, 100])

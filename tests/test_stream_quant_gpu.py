@@ -262,3 +262,26 @@ def test_streaming_per_hop_analysis_equals_chunked(dev):
         assert np.array_equal(cpu(torch.cat(mels, 1)), cpu(b.mel_out))
     with pytest.raises(ValueError):
         StreamingDGTSession(S, 300, n, h, device=dev)
+
+
+def test_streaming_session_draws_its_noise_in_the_kernels(dev):
+    """random_phase_below_tolerance=True: the captured step holds no generator launch -- the RTPGHI kernels draw, the
+    step advances the counter -- and `step(None)` replays on samples the caller wrote into `x_in`."""
+    from acids_transforms_amd.streaming import StreamingDGTSession
+    torch.manual_seed(5)
+    S, C = 4, 256
+    sess = StreamingDGTSession(S, C, device=dev, random_phase_below_tolerance=True, use_graph=True)
+    assert sess.rng_state is not None and sess.graph is not None
+    c0 = int(sess.rng_state[2])
+    tone = 0.5 * torch.sin(2 * torch.pi * 440.0 * torch.arange(8 * C, device=dev) / 44100.0).repeat(S, 1)
+    outs = []
+    for j in range(8):
+        sess.x_in.copy_(tone[:, j * C:(j + 1) * C])
+        outs.append(sess.step(None).clone())
+    assert int(sess.rng_state[2]) == c0 + 8                 # one counter per replay
+    y = torch.cat(outs, -1)
+    assert bool(torch.isfinite(y).all()) and float(y.abs().max()) > 1e-3
+    # a pure tone leaves most bins under the tolerance: their phases are the draws, different every step
+    torch.manual_seed(5)
+    again = StreamingDGTSession(S, C, device=dev, random_phase_below_tolerance=True, use_graph=False)
+    assert torch.equal(again.rng_state[:2], sess.rng_state[:2])    # torch.manual_seed governs the session's seed
