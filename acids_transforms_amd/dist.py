@@ -59,9 +59,9 @@ def all_gather_features(local: torch.Tensor, n_clips_total: int, group=None, asy
     compacted after the collective.  Returns the gathered tensor -- and, when async_op, a
     handle whose `wait()` must be called before the tensor is read (on the ragged path the
     compaction runs inside that `wait()`)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return (local, None) if async_op else local
+    world = dist.get_world_size(group)          # a one-rank group still runs the collective (a copy): same code path
     rank = dist.get_rank(group)
     sizes = [shard_bounds(n_clips_total, r, world)[1] - shard_bounds(n_clips_total, r, world)[0] for r in range(world)]
     assert local.shape[0] == sizes[rank], "local shard has %d clips, expected %d" % (local.shape[0], sizes[rank])

@@ -232,12 +232,31 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
-    if world > 1:
+    # dev only: ACIDS_BENCH_FORCE_DIST=1 runs the RCCL code paths (process group, barriers, max-over-ranks, the config-4
+    # all-gathers) with a world of ONE rank, which a one-GPU box can do -- an API rehearsal, not a measurement
+    use_dist = world > 1 or os.environ.get("ACIDS_BENCH_FORCE_DIST") == "1"
+    if use_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on STDOUT when its communicator comes up; stdout is for the one JSON line, so the
+        # group is created (and its communicator forced up by a first barrier) with fd 1 pointing at stderr
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         backend = dist.get_backend()
         assert dist.get_world_size() == world
     red_dev = torch.device("cpu") if rehearsal else dev
@@ -259,11 +278,11 @@ def main():
     config4 = args.pipeline == "config4"
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def max_over_ranks(seconds):
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([seconds], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
@@ -327,7 +346,7 @@ def main():
         t_compute = timed_region(config4_compute, steps, warmup)
         res["compute_only"] = {"frames_per_s": world * frames_per_step * steps / t_compute,
                                "ms_per_step": t_compute / steps * 1e3}
-        if world > 1 and not rehearsal:
+        if use_dist and not rehearsal:
             comm = torch.cuda.Stream(device=dev)
 
             def with_gather(wire_dtype, what):
@@ -346,7 +365,8 @@ def main():
                             t.record_stream(comm)
                             wire = t if wire_dtype is None else t.to(wire_dtype)
                             _, h = all_gather_features(wire, world * B, async_op=True)
-                            pending.append(h)
+                            if h is not None:
+                                pending.append(h)
 
                 t = timed_region(fn, steps, warmup)
                 for h in pending:
@@ -377,12 +397,12 @@ def main():
                                    "MFCC(40), RCCL all-gather of the features; value = %s" % (world * B, B, key),
                        "n_fft": N_FFT, "hop": HOP, "frames_per_clip": T_FRAMES, "clips_per_gpu": B,
                        "sharding": "clips; all-gather only to reassemble outputs"},
-            "world_size_observed": dist.get_world_size() if world > 1 else 1, "backend": backend,
+            "world_size_observed": dist.get_world_size() if use_dist else 1, "backend": backend,
             "config4": c4,
         }
         if rank == 0:
             print(json.dumps(result))
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -682,7 +702,7 @@ def main():
                                "unipolar)%s + ISTFT invert, fp32" % (B, " [one fused kernel]" if fused else ""),
                    "n_fft": N_FFT, "hop": HOP, "frames_per_clip": T_FRAMES, "clips_per_gpu": B,
                    "sharding": "clips, no data-path collective"},
-        "world_size_observed": dist.get_world_size() if world > 1 else 1, "backend": backend,
+        "world_size_observed": dist.get_world_size() if use_dist else 1, "backend": backend,
         "roofline": roof,
         "kernels": kernels,
     }
@@ -713,7 +733,7 @@ def main():
                 pass
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
