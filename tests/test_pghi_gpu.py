@@ -243,3 +243,17 @@ def test_realtime_seeded_draws_are_standard_normal(dev):
     # with explicit noise the two entry points agree bit for bit on everything above the tolerance
     ref = ops.pghi_realtime(hist, mag, prev, torch.zeros_like(mag), *args)
     assert torch.equal(ref[:, :, 100], a[:, :, 100])
+
+
+def test_winner_bit_kernel_stays_exact(dev):
+    """The opt-in winner-bit heap kernel (ACIDS_PGHI_KERNEL=wbit; the variable is read once per process, hence the child
+    process) must keep producing the C oracle's pop order: ties, sparse spectra, batches of unequal clips."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ACIDS_PGHI_KERNEL="wbit", FUZZ_CASES="24", FUZZ_SEED="3")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pghi.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "24 cases ok" in r.stdout and "identical order" in r.stdout
