@@ -33,6 +33,11 @@ int launch_irfft2048_frames(const float2*, const float*, const float*, long long
                             const float2*, float*, hipStream_t);
 int launch_istft2048_ola(const float2*, const float*, const float*, long long, long long, int, const float*,
                          const float*, const float2*, const float2*, float*, hipStream_t);
+// stft_small.hip (n_fft 256 / 128: four / eight frames per wave-level FFT)
+int launch_stft_small_fwd(int, const float*, long long, long long, long long, long long, int, int, const float*, const float2*,
+                          const float2*, float2*, float*, hipStream_t);
+int launch_irfft_small_frames(int, const float2*, const float*, const float*, long long, const float*, const float2*,
+                              const float2*, float*, hipStream_t);
 // stft512.hip
 int launch_stft512_fwd(const float*, long long, long long, long long, long long, int, int, const float*, const float2*,
                        const float2*, float2*, float*, hipStream_t);
@@ -120,7 +125,19 @@ int at_init(int device) {
     rc = AT_ELAUNCH;
   float2* d2 = nullptr;
   if (rc == AT_OK) {
-    std::vector<float2> t2(1024 + 256);
+    // [0, 1024): W2048^k; [1024, 1280): W512^k; [1280, 1664): W512^(r k), r = 1..3, k < 128 (n_fft 256);
+    // [1664, 2112): W512^(r k), r = 1..7, k < 64 (n_fft 128)
+    std::vector<float2> t2(1024 + 256 + 384 + 448);
+    for (int r = 1; r < 4; ++r)
+      for (int k = 0; k < 128; ++k) {
+        const double a = -two_pi * (double)(r * k) / 512.0;
+        t2[1280 + (r - 1) * 128 + k] = make_float2((float)cos(a), (float)sin(a));
+      }
+    for (int r = 1; r < 8; ++r)
+      for (int k = 0; k < 64; ++k) {
+        const double a = -two_pi * (double)(r * k) / 512.0;
+        t2[1664 + (r - 1) * 64 + k] = make_float2((float)cos(a), (float)sin(a));
+      }
     for (int k = 0; k < 1024; ++k) {
       const double a = -two_pi * (double)k / 2048.0;
       t2[k] = make_float2((float)cos(a), (float)sin(a));
@@ -162,6 +179,13 @@ int at_stft_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, i
     const float2* tw2k = tw2048_for_current_device();
     if (!tw || !tw2k) return AT_ENOTINIT;
     return launch_stft2048_fwd(x, B, L, clip_stride, T, hop, center, window, tw, tw2k, (float2*)out_complex, phase, s);
+  }
+  if ((n_fft == 256 || n_fft == 128) && (((uintptr_t)window) & 7) == 0) {     // four / eight frames per register FFT
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_stft_small_fwd(n_fft, x, B, L, clip_stride, T, hop, center, window, tw, tw2k + (n_fft == 256 ? 1280 : 1664),
+                                 (float2*)out_complex, phase, s);
   }
   if (n_fft == 512 && (((uintptr_t)window) & 7) == 0) {        // two frames per 512-point register FFT
     const float2* tw = twiddles_for_current_device();
@@ -293,6 +317,12 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
     const float2* tw2k = tw2048_for_current_device();
     if (!tw || !tw2k) return AT_ENOTINIT;
     rc = launch_irfft2048_frames((const float2*)X_complex, mag, phase, B * T, inv_window, tw, tw2k, (float*)workspace, s);
+  } else if ((n_fft == 256 || n_fft == 128) && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)workspace) & 7) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    rc = launch_irfft_small_frames(n_fft, (const float2*)X_complex, mag, phase, B * T, inv_window, tw,
+                                   tw2k + (n_fft == 256 ? 1280 : 1664), (float*)workspace, s);
   } else if (n_fft == 512 && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)workspace) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();
     const float2* tw2k = tw2048_for_current_device();
@@ -339,6 +369,13 @@ int at_irfft_frames(const float* X_complex, const float* mag, const float* phase
     const float2* tw2k = tw2048_for_current_device();
     if (!tw || !tw2k) return AT_ENOTINIT;
     return launch_irfft2048_frames((const float2*)X_complex, mag, phase, nframes, inv_window, tw, tw2k, frames, s);
+  }
+  if ((n_fft == 256 || n_fft == 128) && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)frames) & 7) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_irfft_small_frames(n_fft, (const float2*)X_complex, mag, phase, nframes, inv_window, tw,
+                                     tw2k + (n_fft == 256 ? 1280 : 1664), frames, s);
   }
   if (n_fft == 512 && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)frames) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();
