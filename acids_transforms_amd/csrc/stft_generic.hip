@@ -231,6 +231,34 @@ __global__ void ola_gather_kernel(OlaParams p) {
   }
 }
 
+// the same four samples at a time (hop, n_fft multiples of 4, 16-byte aligned buffers): an aligned group of four
+// padded positions never straddles a frame start, so all four samples see the same frames t_lo .. t_hi and the same
+// summation order as the scalar kernel
+__global__ void ola_gather4_kernel(OlaParams p) {
+  const long long out_len = (long long)p.hop * (p.T - 1);
+  const long long total4 = p.B * out_len / 4;
+  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4;
+       i4 += (long long)gridDim.x * blockDim.x) {
+    const long long i = 4 * i4;
+    const long long b = i / out_len, s = i - b * out_len;
+    const long long pp = s + p.n_fft / 2;
+    long long t_hi = pp / p.hop;
+    if (t_hi > p.T - 1) t_hi = p.T - 1;
+    long long t_lo = (pp - p.n_fft + p.hop) / p.hop;
+    if (pp - p.n_fft + 1 <= 0) t_lo = 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), env = acc;
+    for (long long t = t_lo; t <= t_hi; ++t) {
+      const int o = (int)(pp - t * p.hop);
+      if (o < 0 || o >= p.n_fft) continue;
+      const float4 v = *reinterpret_cast<const float4*>(p.frames + (b * p.T + t) * p.n_fft + o);
+      const float4 w = *reinterpret_cast<const float4*>(p.window + o);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      env.x += w.x * w.x; env.y += w.y * w.y; env.z += w.z * w.z; env.w += w.w * w.w;
+    }
+    *reinterpret_cast<float4*>(p.y + i) = make_float4(acc.x / env.x, acc.y / env.y, acc.z / env.z, acc.w / env.w);
+  }
+}
+
 static int set_lds(const void* fn, size_t bytes) {
   if (bytes > 64 * 1024) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
@@ -272,9 +300,12 @@ int launch_ola_gather(const float* frames, long long B, long long T, int n_fft, 
   long long total = B * (long long)hop * (T - 1);
   if (total <= 0) return 0;
   OlaParams p = {frames, window, y, B, T, n_fft, hop};
-  long long blocks = (total + 255) / 256;
+  const bool vec4 = (hop % 4 == 0) && (n_fft % 8 == 0) && (((uintptr_t)frames) & 15) == 0 && (((uintptr_t)window) & 15) == 0 &&
+                    (((uintptr_t)y) & 15) == 0;
+  long long blocks = ((vec4 ? total / 4 : total) + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(ola_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  if (vec4) hipLaunchKernelGGL(ola_gather4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(ola_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
