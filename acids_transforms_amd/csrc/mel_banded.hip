@@ -5,10 +5,12 @@
 // Mel banks -- the reference's default 513 x 513 one included, and its row-normalised transpose used by
 // `invert` -- are banded: column n is non-zero on a short run of rows only.  A dense contraction spends
 // 2 K N flops per frame on what are ~1000 useful multiply-adds; it is MFMA-bound at 5 ms for 1024 clips where
-// the data could stream through in under 1 ms.  Here one wavefront takes one frame at a time: the K (<= 640)
-// input values go through the prologue into a 2.5 KB LDS row, then every lane walks the band of one filter per
-// pass exactly as the fused STFT epilogue does (band_bank.h, utils/banded.py: conflict-free ds_read_b128 of
-// values and weights), and the epilogue writes N outputs.  HBM-bound: the input row in, N floats out.
+// the data could stream through in under 1 ms.  Here one wavefront takes one frame at a time: the K input values
+// (K <= 2112: every n_fft up to 4096) go through the prologue into an LDS row, then every lane walks the band of
+// one filter per pass exactly as the fused STFT epilogue does (band_bank.h, utils/banded.py: conflict-free
+// ds_read_b128 of values and weights), and the epilogue writes N outputs.  HBM-bound: the input row in, N floats
+// out.  The weight table, the lane tables and one row per wave share the 160 KB of LDS; the launcher drops from
+// eight to four waves per workgroup when a long row and a large table would not fit together.
 #include <hip/hip_runtime.h>
 #include "fastmath.h"
 #include <stdint.h>
@@ -30,6 +32,8 @@ struct BandedParams {
   long long rows_per_wave;
   BandBank bank;
   int K, a_kind, contrast, inverse;
+  int row_floats;       // LDS row: the K values + zero padding a walk may run into (multiple of 64)
+  int table_floats;     // 64 * sum(pass_len)
   float eps;
   // optional second output for complex input: normalise(angle(x)), rows of ld_phase floats (Polar: the stacked
   // (.., T, 2, F) tensor is written in place -- magnitudes at row offset 0, phases at row offset F)
@@ -42,9 +46,10 @@ struct BandedParams {
   const float* phase_in;
 };
 
-constexpr int kBandedWaves = 8;     // waves per workgroup, sharing the LDS weight table
-constexpr int kRowFloats = 640;     // LDS row: K values + zero padding a walk may run into
-constexpr int kMaxSeg = kRowFloats / 64;   // 64-element segments per row (10)
+constexpr int kBandedWaves = 8;     // waves per workgroup (at most), sharing the LDS weight table
+constexpr int kMaxRowK = 2112;      // longest input row: 33 segments of 64 (n_fft 4096 -> 2049 bins)
+constexpr int kMaxWalk = 512;       // longest band a lane walks
+constexpr size_t kLdsBudget = 160 * 1024;
 
 __device__ __forceinline__ float banded_contrast_fwd(float v, int mode, float eps) {
   switch (mode) {
@@ -63,24 +68,24 @@ __device__ __forceinline__ float banded_contrast_inv(float v, int mode, float ep
   }
 }
 
-template <bool CPLX, int NSEG>   // NSEG = ceil(K / 64)
+// NSEG >= ceil(K / 64) segments of 64 values per row; EXACT: NSEG == ceil(K / 64) (only the last segment can run
+// past the row's end)
+template <bool CPLX, int NSEG, bool EXACT>
 __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedParams p) {
-  __shared__ float rows_lds[kBandedWaves * kRowFloats];
-  extern __shared__ float4 band_lds[];   // weight table, then lane_start / lane_filter
+  extern __shared__ float4 band_lds[];   // weight table, lane_start / lane_filter, one row per wave
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int n_thr = blockDim.x;
   float* wlds = reinterpret_cast<float*>(band_lds);
-  int table_floats = 0;
-  for (int q = 0; q < p.bank.n_passes; ++q) table_floats += 64 * p.bank.pass_len[q];
-  for (int i = threadIdx.x; i < table_floats; i += 64 * kBandedWaves) wlds[i] = p.bank.weights[i];
+  const int table_floats = p.table_floats;
+  for (int i = threadIdx.x; i < table_floats; i += n_thr) wlds[i] = p.bank.weights[i];
   int* lane_tab = reinterpret_cast<int*>(wlds + table_floats);
-  for (int i = threadIdx.x; i < 64 * p.bank.n_passes; i += 64 * kBandedWaves) {
+  for (int i = threadIdx.x; i < 64 * p.bank.n_passes; i += n_thr) {
     lane_tab[i] = p.bank.lane_start[i];
     lane_tab[64 * p.bank.n_passes + i] = p.bank.lane_filter[i];
   }
-  float* absrow = rows_lds + wave * kRowFloats;
-#pragma unroll
-  for (int m = NSEG; m < kMaxSeg; ++m) absrow[lane + 64 * m] = 0.0f;   // padding behind the K values stays zero
+  float* absrow = reinterpret_cast<float*>(lane_tab + 2 * 64 * p.bank.n_passes) + wave * p.row_floats;
+  for (int k = 64 * NSEG + lane; k < p.row_floats; k += 64) absrow[k] = 0.0f;   // padding behind the row stays zero
   __syncthreads();
 
   float off = 0.f, sc = 1.f;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
     ph_off = *p.ph_offset;
     ph_sc = *p.ph_scale;
   }
-  const long long w_id = (long long)blockIdx.x * kBandedWaves + wave;
+  const long long w_id = (long long)blockIdx.x * (n_thr >> 6) + wave;
   long long r = w_id * p.rows_per_wave;
   long long r_end = r + p.rows_per_wave;
   if (r_end > p.rows) r_end = p.rows;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
 #pragma unroll
     for (int m = 0; m < NSEG; ++m) {
       int k = lane + 64 * m;
-      if (m + 1 == NSEG) k = k < p.K ? k : p.K - 1;
+      if (!EXACT || m + 1 == NSEG) k = k < p.K ? k : p.K - 1;
       v[m] = src[k];
     }
   };
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
         v = (p.a_kind == A_COMPLEX_ABS2) ? s2 : __builtin_amdgcn_sqrtf(s2);
         if (p.phase_out) {
           const int kk = lane + 64 * m;
-          if (m + 1 < NSEG || kk < p.K) {
+          if ((EXACT && m + 1 < NSEG) || kk < p.K) {
             float ph = fast_atan2f(cur[m].y, cur[m].x);
             if (p.ph_offset) ph = (ph - ph_off) / ph_sc;
             p.phase_out[r * p.ld_phase + kk] = ph;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
         }
       }
       const int k = lane + 64 * m;
-      absrow[k] = (m + 1 < NSEG || k < p.K) ? v : 0.0f;
+      absrow[k] = ((EXACT && m + 1 < NSEG) || k < p.K) ? v : 0.0f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -182,16 +187,18 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
   };
   // two register sets swapping roles (a copy of registers with loads in flight would wait for them -- and, memory
   // returning in order, for this row's stores); the last row of a run requests itself again
-  In ra[NSEG], rb[NSEG];
-  if constexpr (!CPLX) {
+  In ra[NSEG];
+  if constexpr (!CPLX || NSEG > 17) {
     // real rows (the inverse projection, |x| inputs): half the bytes per row and exp() per element -- the second
-    // copy of the loop body costs more than the prefetch returns (A/B: 0.73 vs 0.70 ms); occupancy hides the load
+    // copy of the loop body costs more than the prefetch returns (A/B: 0.73 vs 0.70 ms); occupancy hides the load.
+    // The longest complex rows (33 segments: 66 registers a copy) take the same single-buffered loop.
     for (; r < r_end; ++r) {
       fetch(r, ra);
       walk(r, ra);
     }
     return;
-  }
+  } else {
+  In rb[NSEG];
   fetch(r, ra);
   while (r < r_end) {
     fetch(r + 1 < r_end ? r + 1 : r, rb);
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
     walk(r, rb);
     ++r;
   }
+  }
 }
 
 template <bool CPLX>
@@ -208,41 +216,66 @@ static int launch_banded(const BandedParams& p0, size_t dyn_lds, hipStream_t s) 
   BandedParams p = p0;
   const int nseg = (p.K + 63) / 64;
   void (*kernel)(BandedParams) = nullptr;
+  int kseg = nseg;
   switch (nseg) {
-    case 1: kernel = mel_banded_kernel<CPLX, 1>; break;
-    case 2: kernel = mel_banded_kernel<CPLX, 2>; break;
-    case 3: kernel = mel_banded_kernel<CPLX, 3>; break;
-    case 4: kernel = mel_banded_kernel<CPLX, 4>; break;
-    case 5: kernel = mel_banded_kernel<CPLX, 5>; break;
-    case 6: kernel = mel_banded_kernel<CPLX, 6>; break;
-    case 7: kernel = mel_banded_kernel<CPLX, 7>; break;
-    case 8: kernel = mel_banded_kernel<CPLX, 8>; break;
-    case 9: kernel = mel_banded_kernel<CPLX, 9>; break;
-    default: kernel = mel_banded_kernel<CPLX, 10>; break;
+    case 1: kernel = mel_banded_kernel<CPLX, 1, true>; break;
+    case 2: kernel = mel_banded_kernel<CPLX, 2, true>; break;
+    case 3: kernel = mel_banded_kernel<CPLX, 3, true>; break;
+    case 4: kernel = mel_banded_kernel<CPLX, 4, true>; break;
+    case 5: kernel = mel_banded_kernel<CPLX, 5, true>; break;
+    case 6: kernel = mel_banded_kernel<CPLX, 6, true>; break;
+    case 7: kernel = mel_banded_kernel<CPLX, 7, true>; break;
+    case 8: kernel = mel_banded_kernel<CPLX, 8, true>; break;
+    case 9: kernel = mel_banded_kernel<CPLX, 9, true>; break;
+    case 10: kernel = mel_banded_kernel<CPLX, 10, true>; break;
+    case 17: kernel = mel_banded_kernel<CPLX, 17, true>; break;       // n_fft 2048
+    case 33: kernel = mel_banded_kernel<CPLX, 33, true>; break;       // n_fft 4096
+    default:                                                          // in between: the next larger variant
+      if (nseg < 17) { kernel = mel_banded_kernel<CPLX, 17, false>; kseg = 17; }
+      else { kernel = mel_banded_kernel<CPLX, 33, false>; kseg = 33; }
+      break;
   }
+  // LDS: table + lane tables + one row per wave.  The row holds the kernel's segments and whatever a walk that starts
+  // on the row's last bins can run into.
+  int max_walk = 0;
+  for (int q = 0; q < p.bank.n_passes; ++q) max_walk = p.bank.pass_len[q] > max_walk ? p.bank.pass_len[q] : max_walk;
+  // (idle lanes are parked on the first 16 quads of the row and walk like the others)
+  const int reach = (p.K > 64 ? p.K : 64) + max_walk > 64 * kseg ? (p.K > 64 ? p.K : 64) + max_walk : 64 * kseg;
+  p.row_floats = (reach + 63) / 64 * 64;
+  int waves_per_block = kBandedWaves;
+  while (waves_per_block > 1 && dyn_lds + (size_t)waves_per_block * p.row_floats * sizeof(float) > kLdsBudget) waves_per_block >>= 1;
+  dyn_lds += (size_t)waves_per_block * p.row_floats * sizeof(float);
+  if (dyn_lds > kLdsBudget) return AT_EUNSUPPORTED;
   // wave slots of this variant (occupancy x CUs), looked up once per (kernel, table size)
-  struct Entry { const void* k; size_t lds; long long slots; };
+  struct Entry { const void* k; size_t lds; int dev; long long slots; };
   static thread_local Entry cache[16];
   static thread_local int n_cached = 0;
   long long slots = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return AT_ELAUNCH;
   for (int i = 0; i < n_cached; ++i)
-    if (cache[i].k == (const void*)kernel && cache[i].lds == dyn_lds) slots = cache[i].slots;
+    if (cache[i].k == (const void*)kernel && cache[i].lds == dyn_lds && cache[i].dev == dev) slots = cache[i].slots;
   if (!slots) {
-    int cus = 256, dev = 0, nb = 0;
+    int cus = 256, nb = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * kBandedWaves, dyn_lds) != hipSuccess || nb <= 0) nb = 2;
-    slots = (long long)cus * nb * kBandedWaves;
-    if (n_cached < 16) cache[n_cached++] = {(const void*)kernel, dyn_lds, slots};
+    if (dyn_lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return AT_ELAUNCH;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * waves_per_block, dyn_lds) != hipSuccess || nb <= 0) nb = 1;
+    slots = (long long)cus * nb * waves_per_block;
+    if (n_cached < 16) cache[n_cached++] = {(const void*)kernel, dyn_lds, dev, slots};
   }
   // a few whole rounds of resident waves: the table staging of a block is amortised and the tail stays short
   long long rpw = (p.rows + 4 * slots - 1) / (4 * slots);
   if (rpw < 8) rpw = 8;
   p.rows_per_wave = rpw;
   const long long waves = (p.rows + rpw - 1) / rpw;
-  const long long blocks = (waves + kBandedWaves - 1) / kBandedWaves;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * kBandedWaves), dyn_lds, s, p);
+  const long long blocks = (waves + waves_per_block - 1) / waves_per_block;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), dyn_lds, s, p);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
@@ -267,7 +300,7 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
   if (phase_out && a_kind >= A_REAL) return AT_EINVAL;
   if (phase_in && (!inverse || phase_out || T_transposed)) return AT_EINVAL;
   if ((phase_offset == nullptr) != (phase_scale == nullptr)) return AT_EINVAL;
-  if (K > kRowFloats || (((uintptr_t)band_weights) & 15)) return AT_EUNSUPPORTED;
+  if (K > kMaxRowK || (((uintptr_t)band_weights) & 15)) return AT_EUNSUPPORTED;
   BandedParams p = {};
   p.A = A; p.out = out; p.offset = offset; p.scale = scale;
   p.rows = rows; p.lda = lda; p.ld_out = ld_out; p.T = T_transposed;
@@ -278,11 +311,11 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
   p.phase_in = phase_in;
   size_t table_floats = 0;
   for (int q = 0; q < n_passes; ++q) {
-    if (pass_len_host[q] < 0 || pass_len_host[q] > 128 || (pass_len_host[q] & 3)) return AT_EINVAL;
+    if (pass_len_host[q] < 0 || pass_len_host[q] > kMaxWalk || (pass_len_host[q] & 3)) return AT_EINVAL;
     p.bank.pass_len[q] = pass_len_host[q];
     table_floats += (size_t)64 * pass_len_host[q];
   }
-  if (table_floats > (size_t)kMaxBandFloats) return AT_EUNSUPPORTED;
+  p.table_floats = (int)table_floats;
   const size_t dyn_lds = table_floats * sizeof(float) + (size_t)2 * 64 * n_passes * sizeof(int);
   hipStream_t s = (hipStream_t)stream;
   return a_kind >= A_REAL ? launch_banded<false>(p, dyn_lds, s) : launch_banded<true>(p, dyn_lds, s);

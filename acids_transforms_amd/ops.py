@@ -181,7 +181,7 @@ def mel_forward(x, bank, contrast=None, offset=None, scale=None, eps=1.1920929e-
     x = _prep_in(x)
     K, N = bank.shape[-2], bank.shape[-1]
     assert x.shape[-1] == K, "last dim of the input (%d) must match the bank (%d)" % (x.shape[-1], K)
-    if band is not None and band.eligible and K <= 640:
+    if band is not None and band.eligible:
         shape = (x.shape[:-2] + (N, channel_major_T)) if channel_major_T else (x.shape[:-1] + (N,))
         out = _out_buffer(out, shape, x.device)
         return _project_banded(x, _a_kind(x, power), band, contrast, False, offset, scale, eps, out, N, channel_major_T)
@@ -229,7 +229,7 @@ def mel_inverse(y, inv_bank, contrast=None, offset=None, scale=None, eps=1.19209
     y = _prep_in(y)
     K, N = inv_bank.shape[-2], inv_bank.shape[-1]
     assert y.shape[-1] == K
-    if band is not None and band.eligible and K <= 640:
+    if band is not None and band.eligible:
         out = torch.empty(y.shape[:-1] + (N,), dtype=torch.float32, device=y.device)
         return _project_banded(y, 2, band, contrast, True, offset, scale, eps, out, N, 0)
     b2 = inv_bank.reshape(K, N)

@@ -88,7 +88,7 @@ class MFCC(AudioTransform):
     def forward(self, x: torch.Tensor):
         self._follow(x)
         xb, batch_shape = reshape_batches(x, -1)
-        fusable = (self.n_fft == 1024 and self.hop_length == 256 and self._band.eligible
+        fusable = (self.n_fft == 1024 and self.hop_length == 256 and self._band.fusable
                    and xb.dtype == torch.float32 and xb.shape[-1] > 512 and not (xb.shape[-1] & 1))
         if fusable and self.n_mfcc is None:
             # one kernel, audio -> mel power: the spectrum never goes to HBM

@@ -115,7 +115,8 @@ class Magnitude(AudioTransform):
         enough, or when this module's options rule the fusion out)."""
         if not self.mel or not self.keep_nyquist or self.bank_dtype != "fp32":
             return None
-        return self._band_of("mel_bank")
+        band = self._band_of("mel_bank")
+        return band if band is not None and band.fusable else None
 
     def can_fuse_with(self, stage, x: torch.Tensor) -> bool:
         """True when `stage` (an offline STFT/DGT with n_fft=1024 and hop 256, 128 or 512) followed by this module can

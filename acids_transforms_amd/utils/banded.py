@@ -1,4 +1,4 @@
-"""Banded view of a (K x N) filterbank for the fused STFT -> mel kernel.
+"""Banded view of a (K x N) filterbank for the fused STFT -> mel kernel and the stand-alone banded projection.
 
 Mel filterbanks are banded: column n is zero outside a short run of frequency rows.  The fused
 forward kernel exploits exactly that (and nothing else): after the FFT a wave holds |X| of one frame
@@ -22,14 +22,22 @@ collision-free choice exist in practice.  `lds_read_cycles()` evaluates the resu
 banking model, so the property is testable without a GPU.
 
 A bank that is not banded enough reports `eligible = False` and the dense MFMA projection
-(`at_mel_project`) is used instead.
+(`at_mel_project`) is used instead.  `eligible` is what the stand-alone projection (mel_banded.hip) takes: rows
+of up to 2112 bins (n_fft <= 4096), up to 40 passes, bands of up to 512 bins, as long as the weight table, the lane
+tables and four rows fit the 160 KB of LDS.  `fusable` is the tighter set the fused n_fft = 1024 epilogue
+(stft1024.hip) takes: 16 passes, bands of 128 bins, a 32 KB weight table next to the FFT slabs.
 """
 import numpy as np
 import torch
 
-MAX_PASSES = 16       # filters per lane (N <= 1024; the reference's default bank has 513)
-MAX_BAND = 128        # longest band a lane will walk
-MAX_TABLE_FLOATS = 8192   # LDS copy of the weights (kMaxBandFloats in stft1024.hip), dynamic LDS
+MAX_PASSES = 40       # filters per lane (kMaxBandPasses in band_bank.h: N <= 2560; the default bank has n_fft/2+1)
+MAX_BAND = 512        # longest band a lane will walk (kMaxWalk in mel_banded.hip)
+MAX_ROW = 2112        # longest input row (kMaxRowK)
+LDS_BUDGET = 160 * 1024
+FUSED_MAX_PASSES = 16     # the fused epilogue of stft1024.hip: kMaxFusedPasses,
+FUSED_MAX_BAND = 128      # its longest walk,
+FUSED_TABLE_FLOATS = 8192  # its LDS copy of the weights (kMaxBandFloats)
+FUSED_ROW_FLOATS = 640    # and the |X| row a walk may run over
 # lanes served together by one LDS cycle of a ds_read_b128 (MI355X_MICROARCH.md, LDS table)
 B128_GROUPS = (
     (0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27),
@@ -122,8 +130,8 @@ class BandedBank:
         self.lmax = int((n_quads * 4).max()) if N else 0
         self.n_passes = (N + 63) // 64
         self.executed_macs = int(np.where(has, last - first + 1, 0).sum())   # useful multiply-adds per frame
-        self.eligible = False
-        if not (0 < N and self.n_passes <= MAX_PASSES and self.lmax <= MAX_BAND):
+        self.eligible = self.fusable = False
+        if not (0 < N and self.n_passes <= MAX_PASSES and self.lmax <= MAX_BAND and K <= MAX_ROW):
             return
         # passes: filters sorted by band length, 64 per pass, so that every pass walks bands of similar length
         order = np.argsort(-n_quads, kind="stable")
@@ -151,9 +159,16 @@ class BandedBank:
                 w[:, lane, :] = col.reshape(walk, 4)
             tables.append(w.reshape(-1))
         weights = np.concatenate(tables) if tables else np.zeros(0, np.float32)
-        if weights.size > MAX_TABLE_FLOATS or int(lane_start.max()) + int(pass_len.max()) > 640:
+        # the LDS plan of mel_banded.hip (launch_banded): table + lane tables + at least four rows
+        segs = (K + 63) // 64
+        kernel_segs = segs if segs <= 10 else (17 if segs <= 17 else 33)
+        row_floats = -(-max(max(K, 64) + int(pass_len.max()), 64 * kernel_segs) // 64) * 64
+        if weights.size * 4 + 2 * 64 * self.n_passes * 4 + 4 * row_floats * 4 > LDS_BUDGET:
             return
         self.eligible = True
+        self.fusable = (self.n_passes <= FUSED_MAX_PASSES and self.lmax <= FUSED_MAX_BAND
+                        and weights.size <= FUSED_TABLE_FLOATS
+                        and int(lane_start.max()) + int(pass_len.max()) <= FUSED_ROW_FLOATS)
         self.pass_len = pass_len                              # host array handed to the C ABI
         self.walked_macs = 64 * int(pass_len.sum())           # multiply-adds issued per frame (incl. zeros)
         self._host = (lane_filter, lane_start, weights)

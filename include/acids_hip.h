@@ -255,9 +255,12 @@ int at_onehot(const int64_t *x, int64_t n, int classes, int64_t channel_major_in
 int at_argmax_last(const int64_t *x_i64, const float *x_f32, int64_t rows, int cols, int64_t *out, void *stream);
 
 /* The same projection for a BANDED bank (mel banks, the reference's default 513 x 513 one and its inverse
- * included): the K <= 640 inputs of a frame go through the prologue into LDS and every lane walks the band of
+ * included): the K inputs of a frame go through the prologue into LDS and every lane walks the band of
  * one filter per pass -- the walk tables are those of at_stft_mel_forward (utils/banded.py).  HBM-bound (input
  * row in, n_filters floats out) where the dense contraction is MFMA-bound.  Arguments as at_mel_project.
+ * Limits (wider than the fused epilogue's): K <= 2112 (every n_fft up to 4096), n_passes <= 40, pass_len <= 512,
+ * and weight table + lane tables + one LDS row per wave within 160 KB (AT_EUNSUPPORTED otherwise: use
+ * at_mel_project).
  * phase_out != NULL (complex input): also writes normalise(angle(x)) with row stride ld_phase -- Polar.forward
  * (spectral_repr.py:432-439) fills its stacked (.., T, 2, F) result in one pass over the spectrum.
  * phase_in != NULL (inverse only): `out` is complex64, out[r, f] = acc * exp(i * (phase_in[r*ld_phase + f] *

@@ -371,23 +371,51 @@ def test_fused_stft_mel_at_other_hops(dev, hop):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_fft", [256, 2048, 4096])
+@pytest.mark.parametrize("n_fft", [256, 512, 1536, 2048, 3000, 4096, 8192])
 def test_magnitude_at_other_fft_sizes(dev, n_fft):
     """Magnitude(n_fft != 1024): the reference-default F x F bank and an 80-mel one, forward and invert against the
-    oracle -- banded walk while a frame fits the LDS row (F <= 640), the dense MFMA projection above that."""
+    oracle -- banded walk while a frame fits the LDS row (F <= 2112: the 17- and 33-segment kernels, exact at 2048 /
+    4096 and clamped for the sizes in between), the dense MFMA projection above that."""
+    from acids_transforms_amd.utils.banded import BandedBank
     F = n_fft // 2 + 1
     torch.manual_seed(n_fft)
-    X = (torch.randn(2, 9, F) + 1j * torch.randn(2, 9, F)).to(torch.complex64)
+    X = (torch.randn(3, 37, F) + 1j * torch.randn(3, 37, F)).to(torch.complex64)
     for kw in ({}, {"n_mels": 80}):
         mg = A.Magnitude(n_fft=n_fft, **kw).to(dev)
         mg.scale_data(X.to(dev))
-        assert (mg._band_of("mel_bank") is not None) == (F <= 640)
+        assert (mg._band_of("mel_bank") is not None) == (F <= 2112)
+        assert (mg._band_of("inverse_mel_bank") is not None) == (F <= 2112)
+        assert BandedBank(mg.mel_bank).fusable == (F <= 513)          # the fused epilogue keeps its tighter limits
         fwd, inv = O.magnitude_banks(O.melscale_fbanks(F, 0.0, 22050.0, kw.get("n_mels", F), 44100))
         off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
         yr = O.magnitude_forward(X, fwd, "log1p", off, sc)
         y = mg(X.to(dev))
         assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL
         assert rel_max(cpu(mg.invert(y)), O.magnitude_invert(yr, inv, "log1p", off, sc).numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft", [1536, 2048, 4096])
+def test_polar_one_pass_at_long_rows(dev, n_fft):
+    """Polar over the spectra of the larger FFTs: still one banded pass each way (magnitude + angle into the stacked
+    tensor; de-normalise, project, attach the phase), same values as the parts."""
+    from acids_transforms_amd import ops
+    F = n_fft // 2 + 1
+    gen = torch.Generator().manual_seed(n_fft)
+    X = (torch.randn(2, 29, F, generator=gen) * torch.exp(2j * np.pi * torch.rand(2, 29, F, generator=gen))).to(torch.complex64)
+    Xd = X.to(dev)
+    pol = A.Polar(magnitude_args={"mode": "bipolar", "n_fft": n_fft}).to(dev)
+    pol.scale_data(Xd)
+    assert pol._one_pass(Xd) is not None
+    y = pol(Xd)
+    assert y.shape == (2, 29, 2, F)
+    assert rel_max(cpu(y[..., 0, :]), cpu(pol.magnitude(Xd))) < TOL
+    po, ps = O.normalize_stats(X.angle(), "bipolar")
+    assert rel_max(cpu(y[..., 1, :]), O.affine(X.angle(), po, ps).numpy()) < TOL
+    assert pol._one_pass_invert(y) is not None
+    Xi = pol.invert(y)
+    parts = ops.polar_to_complex(pol.magnitude.invert(y[..., 0, :]), pol.phase.invert(y[..., 1, :]))
+    assert rel_max(cpu(Xi), cpu(parts)) < TOL
 
 
 # ----------------------------------------------------------------------------------------------------------
