@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ACIDS_HIP_LIB") or os.path.join(_HERE, "libacids_hip.so")   # override: kernel A/B experiments
 
-ABI_VERSION = 2            # what this binding was written against (include/acids_hip.h, at_abi_version())
+ABI_VERSION = 3            # what this binding was written against (include/acids_hip.h, at_abi_version())
 
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_i64 = ctypes.c_int64
@@ -38,6 +38,10 @@ _SIGNATURES = {
     "at_phase_scan": [c_f, c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_f],
     "at_phase_integrate": [c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_polar_to_complex": [c_f, c_f, c_i64, c_f, c_f],
+    "at_phase_scan_strided": [c_f, c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_i64, c_f],
+    "at_phase_integrate_polar": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_f, c_f, c_f, c_f, c_f],
+    "at_cartesian_pack": [c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f],
+    "at_cartesian_unpack": [c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f],
     "at_resample_sinc": [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, c_i64, c_f, c_f],
     "at_sinebank_workspace_bytes": [c_i64, c_int, c_i64, c_int],
     "at_sinebank_offline": [c_f, c_i64, c_i64, c_int, c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_sz, c_f],

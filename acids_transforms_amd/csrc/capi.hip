@@ -23,6 +23,9 @@ int launch_irfft1024_frames(const float2*, const float*, const float*, long long
 // stft_generic.hip
 int launch_rfft_generic(const float*, long long, long long, long long, long long, int, int, int, const float*,
                         float2*, float*, hipStream_t);
+int launch_rfft_mixed(const float*, long long, long long, long long, long long, int, int, int, const float*, float2*,
+                      float*, hipStream_t);
+int launch_irfft_mixed(const float2*, const float*, const float*, long long, int, const float*, float*, hipStream_t);
 int launch_irfft_generic(const float2*, const float*, const float*, long long, int, const float*, float*,
                          hipStream_t);
 int launch_ola_gather(const float*, long long, long long, int, int, const float*, float*, hipStream_t);
@@ -63,6 +66,10 @@ static const float2* tw2048_for_current_device() {
 }
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+// every n_fft in [2, 16384] (odd sizes, transformed at full length, up to 8191: two LDS copies of the frame)
+static bool fft_size_ok(int n) { return n >= 2 && n <= 16384 && (!(n & 1) || n < 8192); }
+// sizes the mixed-radix kernels of stft_mixed.hip take (everything that is not a power of two >= 8)
+static bool fft_mixed(int n) { return !is_pow2(n) || n < 8; }
 
 __global__ void envelope_table_kernel(const float* w, int n_fft, int hop, int R, float* env) {
   // env[mask][r] = sum over q in mask (ascending) of w[hop*(R-1-q) + r]^2: the R = n_fft / hop frames that overlap a
@@ -84,7 +91,9 @@ using namespace at_hip;
 
 extern "C" {
 
-int at_abi_version(void) { return 2; }   // 2: at_sinebank_realtime takes the synthesis window; bf16 projection, at_oadd_push
+// 2: at_sinebank_realtime takes the synthesis window; bf16 projection, at_oadd_push
+// 3: any n_fft (odd sizes give torch.istft's hop (T-1) + 1 samples); Cartesian pack / unpack; strided phase scans
+int at_abi_version(void) { return 3; }
 
 const char* at_error_string(int code) {
   switch (code) {
@@ -163,7 +172,7 @@ int at_stft_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, i
   if (B < 0 || T < 0 || L < 0 || hop <= 0 || n_fft <= 0) return AT_EINVAL;
   if (B * T == 0) return AT_OK;
   if (!x || !window || !out_complex) return AT_EINVAL;
-  if (!is_pow2(n_fft) || n_fft < 8 || n_fft > 16384) return AT_EUNSUPPORTED;
+  if (!fft_size_ok(n_fft)) return AT_EUNSUPPORTED;
   if (center && L <= n_fft / 2) return AT_EINVAL;  // torch.stft: reflect pad must be < L
   hipStream_t s = (hipStream_t)stream;
   if (n_fft == 1024 && (((uintptr_t)window) & 7) == 0) {
@@ -193,6 +202,8 @@ int at_stft_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, i
     if (!tw || !tw2k) return AT_ENOTINIT;
     return launch_stft512_fwd(x, B, L, clip_stride, T, hop, center, window, tw, tw2k + 1024, (float2*)out_complex, phase, s);
   }
+  if (fft_mixed(n_fft))
+    return launch_rfft_mixed(x, B, L, clip_stride, T, n_fft, hop, center, window, (float2*)out_complex, phase, s);
   return launch_rfft_generic(x, B, L, clip_stride, T, n_fft, hop, center, window, (float2*)out_complex, phase, s);
 }
 
@@ -286,10 +297,10 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
              const float* inv_window, const float* env16, float* y, void* workspace, size_t workspace_bytes,
              void* stream) {
   if (B < 0 || T < 0 || hop <= 0 || n_fft <= 0) return AT_EINVAL;
-  if (B == 0 || T <= 1) return AT_OK;
+  if (B == 0 || T == 0 || (T == 1 && !(n_fft & 1))) return AT_OK;     // hop * (T - 1) + (n_fft & 1) samples per clip
   if (!inv_window || !y) return AT_EINVAL;
   if (!X_complex && !(mag && phase)) return AT_EINVAL;
-  if (!is_pow2(n_fft) || n_fft < 8 || n_fft > 16384) return AT_EUNSUPPORTED;
+  if (!fft_size_ok(n_fft)) return AT_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (istft_fast(n_fft, hop, env16, inv_window) && (((uintptr_t)y) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();
@@ -328,6 +339,8 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
     const float2* tw2k = tw2048_for_current_device();
     if (!tw || !tw2k) return AT_ENOTINIT;
     rc = launch_irfft512_frames((const float2*)X_complex, mag, phase, B * T, inv_window, tw, tw2k + 1024, (float*)workspace, s);
+  } else if (fft_mixed(n_fft)) {
+    rc = launch_irfft_mixed((const float2*)X_complex, mag, phase, B * T, n_fft, inv_window, (float*)workspace, s);
   } else {
     rc = launch_irfft_generic((const float2*)X_complex, mag, phase, B * T, n_fft, inv_window, (float*)workspace, s);
   }
@@ -357,7 +370,7 @@ int at_irfft_frames(const float* X_complex, const float* mag, const float* phase
   if (nframes == 0) return AT_OK;
   if (!inv_window || !frames) return AT_EINVAL;
   if (!X_complex && !(mag && phase)) return AT_EINVAL;
-  if (!is_pow2(n_fft) || n_fft < 8 || n_fft > 16384) return AT_EUNSUPPORTED;
+  if (!fft_size_ok(n_fft)) return AT_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (n_fft == 1024 && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)frames) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();
@@ -383,6 +396,8 @@ int at_irfft_frames(const float* X_complex, const float* mag, const float* phase
     if (!tw || !tw2k) return AT_ENOTINIT;
     return launch_irfft512_frames((const float2*)X_complex, mag, phase, nframes, inv_window, tw, tw2k + 1024, frames, s);
   }
+  if (fft_mixed(n_fft))
+    return launch_irfft_mixed((const float2*)X_complex, mag, phase, nframes, n_fft, inv_window, frames, s);
   return launch_irfft_generic((const float2*)X_complex, mag, phase, nframes, n_fft, inv_window, frames, s);
 }
 

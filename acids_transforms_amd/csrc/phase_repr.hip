@@ -34,6 +34,7 @@ struct ScanParams {
   const float* offset;   // optional Normalize affine (device scalars)
   const float* scale;
   int bare;              // 1: plain fdiff_* of a real signal (no unwrap, no per-row division): utils/misc.py:65-81
+  long long ld_out;      // floats between consecutive frames of `out` (F, or 2 F inside a stacked (.., T, 2, F) tensor)
 };
 
 // the correction torch's unwrap adds for one frame-to-frame jump (utils/misc.py:19-24)
@@ -72,10 +73,12 @@ __global__ __launch_bounds__(256) void phase_scan_kernel(ScanParams p) {
     sc = *p.scale;
   }
   const bool div = !p.bare;
+  float* out_col = p.out + b * p.T * p.ld_out + f;
+  const long long ldo = p.ld_out;
   auto emit = [&](long long t, float v) {
     if (WIN) v = p.window[t] * v;
     if (NORM) v = (v - off) / sc;
-    p.out[base + t * F] = v;
+    out_col[t * ldo] = v;
   };
   using In = typename std::conditional<CPLX, float2, float>::type;
   const In* src = (CPLX ? reinterpret_cast<const In*>(p.X) : reinterpret_cast<const In*>(p.phase)) + base;
@@ -153,20 +156,40 @@ __global__ __launch_bounds__(256) void phase_angle_kernel(ScanParams p) {
     }
     if (p.window) v = p.window[(i / p.F) % p.T] * v;
     if (norm) v = (v - off) / sc;
-    p.out[i] = v;
+    if (p.ld_out == p.F) {
+      p.out[i] = v;
+    } else {
+      const long long row = i / p.F;
+      p.out[row * p.ld_out + (i - row * p.F)] = v;
+    }
   }
 }
 
 // ---- integration (IF.invert) -------------------------------------------------------------------------
 struct IntParams {
   const float* y;        // (B, T, F) instantaneous frequency (normalised when offset/scale are given)
-  float* out;
+  float* out;            // (B, T, F) phase -- or complex64 mag * exp(i phase) when `mag` is given
   long long B, T, F;
   const float* offset;
   const float* scale;
+  long long ld_y;        // floats between consecutive frames of y (F, or 2 F inside a stacked tensor)
+  const float* mag;      // optional (B, T, F) contiguous magnitudes
 };
 
-template <int METHOD, bool NORM>   // SCAN_IF_*; `rescale` = 0 gives the bare fint_* of utils/misc.py
+// the integrated phase of one bin goes out as it is, or as mag * exp(i phase) (PolarIF.invert in one pass)
+template <bool POLAR>
+__device__ __forceinline__ void put_phase(const IntParams& p, long long idx, float ph) {
+  if constexpr (POLAR) {
+    float sn, cs;
+    sincosf(ph, &sn, &cs);
+    const float m = p.mag[idx];
+    reinterpret_cast<float2*>(p.out)[idx] = make_float2(m * cs, m * sn);
+  } else {
+    p.out[idx] = ph;
+  }
+}
+
+template <int METHOD, bool NORM, bool POLAR>   // SCAN_IF_*; `rescale` = 0 gives the bare fint_* of utils/misc.py
 __global__ __launch_bounds__(256) void phase_integrate_kernel(IntParams p, int rescale) {
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= p.B * p.F) return;
@@ -178,7 +201,8 @@ __global__ __launch_bounds__(256) void phase_integrate_kernel(IntParams p, int r
     off = *p.offset;
     sc = *p.scale;
   }
-  const float* src = p.y + base;
+  const float* src = p.y + b * p.T * p.ld_y + f;
+  const long long ldy = p.ld_y;
   // de-normalised, re-scaled value of input row t (spectral_repr.py:362-370)
   auto prep = [&](long long t, float v) {
     if (NORM) v = v * sc + off;
@@ -198,60 +222,60 @@ __global__ __launch_bounds__(256) void phase_integrate_kernel(IntParams p, int r
       v = prep(row, v);
       if (s >= 1) v = v * 2.0f;
       acc += (double)v;
-      p.out[base + row * F] = (float)acc;
+      put_phase<POLAR>(p, base + row * F, (float)acc);
     };
     long long s = 0;
     for (; s + kRowsAhead <= T; s += kRowsAhead) {
       float v[kRowsAhead];
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(FWD ? s + k : T - 1 - s - k) * F];
+      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(FWD ? s + k : T - 1 - s - k) * ldy];
 #pragma unroll
       for (int k = 0; k < kRowsAhead; ++k) step(s + k, v[k]);
     }
-    for (; s < T; ++s) step(s, src[(FWD ? s : T - 1 - s) * F]);
+    for (; s < T; ++s) step(s, src[(FWD ? s : T - 1 - s) * ldy]);
   } else {
     // fint_central (utils/misc.py:96-104), statement by statement.  Rows the reference never writes stay 0.
-    auto z = [&](long long t) { return prep(t, src[t * F]); };
+    auto z = [&](long long t) { return prep(t, src[t * ldy]); };
     if (T == 1) {
-      p.out[base] = z(0);
+      put_phase<POLAR>(p, base, z(0));
       return;
     }
     float even = z(0);                       // out[0]
-    p.out[base] = even;
+    put_phase<POLAR>(p, base, even);
     long long i = 2;
     for (; i + 2 * (kRowsAhead - 1) < T; i += 2 * kRowsAhead) {   // out[i] = out[i-2] + 4 x[i-1]
       float v[kRowsAhead];
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(i + 2 * k - 1) * F];
+      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(i + 2 * k - 1) * ldy];
 #pragma unroll
       for (int k = 0; k < kRowsAhead; ++k) {
         even = even + 4.0f * prep(i + 2 * k - 1, v[k]);
-        p.out[base + (i + 2 * k) * F] = even;
+        put_phase<POLAR>(p, base + (i + 2 * k) * F, even);
       }
     }
     for (; i < T; i += 2) {
       even = even + 4.0f * z(i - 1);
-      p.out[base + i * F] = even;
+      put_phase<POLAR>(p, base + i * F, even);
     }
-    for (long long j = 1; j < T; j += 2) p.out[base + j * F] = 0.0f;
+    for (long long j = 1; j < T; j += 2) put_phase<POLAR>(p, base + j * F, 0.0f);
     // out[T-1]: x[T-1] when T is even (the forward chain only touched even rows), else the chain's last value
     float cur = ((T - 1) & 1) ? z(T - 1) : even;
-    p.out[base + (T - 1) * F] = cur;
+    put_phase<POLAR>(p, base + (T - 1) * F, cur);
     i = T - 1;
     for (; i - 2 * (kRowsAhead - 1) >= 1; i -= 2 * kRowsAhead) {   // out[i-2] = out[i] - 4 x[i-1]; i = 1 writes row "-1"
       float v[kRowsAhead];
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(i - 2 * k - 1) * F];
+      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(i - 2 * k - 1) * ldy];
 #pragma unroll
       for (int k = 0; k < kRowsAhead; ++k) {
         const long long ii = i - 2 * k;
         cur = cur - 4.0f * prep(ii - 1, v[k]);
-        p.out[base + ((ii - 2 >= 0) ? ii - 2 : T - 1) * F] = cur;
+        put_phase<POLAR>(p, base + ((ii - 2 >= 0) ? ii - 2 : T - 1) * F, cur);
       }
     }
     for (; i >= 1; i -= 2) {
       cur = cur - 4.0f * z(i - 1);
-      p.out[base + ((i - 2 >= 0) ? i - 2 : T - 1) * F] = cur;
+      put_phase<POLAR>(p, base + ((i - 2 >= 0) ? i - 2 : T - 1) * F, cur);
     }
   }
 }
@@ -298,17 +322,16 @@ static void launch_scan(int mode, bool cplx, bool win, bool norm, dim3 grid, dim
 
 using namespace at_hip;
 
-extern "C" {
-
-int at_phase_scan(const float* X_complex, const float* phase, int64_t B, int64_t T, int64_t F, int mode, int bare,
-                  const float* frame_window, const float* offset, const float* scale, float* out, void* stream) {
-  if (B < 0 || T < 0 || F < 0) return AT_EINVAL;
+static int phase_scan_impl(const float* X_complex, const float* phase, int64_t B, int64_t T, int64_t F, int mode, int bare,
+                           const float* frame_window, const float* offset, const float* scale, float* out, int64_t ld_out,
+                           void* stream) {
+  if (B < 0 || T < 0 || F < 0 || ld_out < F) return AT_EINVAL;
   if (B * T * F == 0) return AT_OK;
   if ((X_complex == nullptr) == (phase == nullptr) || !out) return AT_EINVAL;
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
   if (mode < SCAN_UNWRAP || mode > SCAN_ANGLE) return AT_EINVAL;
   if (bare && (mode < SCAN_IF_FORWARD || mode > SCAN_IF_CENTRAL || !phase)) return AT_EINVAL;
-  ScanParams p = {(const float2*)X_complex, phase, out, B, T, F, frame_window, offset, scale, bare};
+  ScanParams p = {(const float2*)X_complex, phase, out, B, T, F, frame_window, offset, scale, bare, ld_out};
   if (mode == SCAN_ANGLE) {
     long long blocks = (B * T * F + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
@@ -322,24 +345,51 @@ int at_phase_scan(const float* X_complex, const float* phase, int64_t B, int64_t
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
-int at_phase_integrate(const float* y, int64_t B, int64_t T, int64_t F, int method, int rescale, const float* offset,
-                       const float* scale, float* out, void* stream) {
-  if (B < 0 || T < 0 || F < 0) return AT_EINVAL;
+template <bool POLAR>
+static int phase_integrate_impl(const float* y, int64_t ld_y, int64_t B, int64_t T, int64_t F, int method, int rescale,
+                                const float* offset, const float* scale, const float* mag, float* out, void* stream) {
+  if (B < 0 || T < 0 || F < 0 || ld_y < F) return AT_EINVAL;
   if (B * T * F == 0) return AT_OK;
-  if (!y || !out || y == out) return AT_EINVAL;
+  if (!y || !out || y == out || (POLAR && !mag)) return AT_EINVAL;
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
   if (method < SCAN_IF_FORWARD || method > SCAN_IF_CENTRAL) return AT_EINVAL;
-  IntParams p = {y, out, B, T, F, offset, scale};
+  IntParams p = {y, out, B, T, F, offset, scale, ld_y, mag};
   const long long cols = B * F;
   const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool norm = offset != nullptr;
   void (*kernel)(IntParams, int) = nullptr;
-  if (method == SCAN_IF_FORWARD) kernel = norm ? phase_integrate_kernel<SCAN_IF_FORWARD, true> : phase_integrate_kernel<SCAN_IF_FORWARD, false>;
-  else if (method == SCAN_IF_BACKWARD) kernel = norm ? phase_integrate_kernel<SCAN_IF_BACKWARD, true> : phase_integrate_kernel<SCAN_IF_BACKWARD, false>;
-  else kernel = norm ? phase_integrate_kernel<SCAN_IF_CENTRAL, true> : phase_integrate_kernel<SCAN_IF_CENTRAL, false>;
+  if (method == SCAN_IF_FORWARD)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_FORWARD, true, POLAR> : phase_integrate_kernel<SCAN_IF_FORWARD, false, POLAR>;
+  else if (method == SCAN_IF_BACKWARD)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_BACKWARD, true, POLAR> : phase_integrate_kernel<SCAN_IF_BACKWARD, false, POLAR>;
+  else
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_CENTRAL, true, POLAR> : phase_integrate_kernel<SCAN_IF_CENTRAL, false, POLAR>;
   hipLaunchKernelGGL(kernel, grid, block, 0, s, p, rescale);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+extern "C" {
+
+int at_phase_scan(const float* X_complex, const float* phase, int64_t B, int64_t T, int64_t F, int mode, int bare,
+                  const float* frame_window, const float* offset, const float* scale, float* out, void* stream) {
+  return phase_scan_impl(X_complex, phase, B, T, F, mode, bare, frame_window, offset, scale, out, F, stream);
+}
+
+int at_phase_scan_strided(const float* X_complex, const float* phase, int64_t B, int64_t T, int64_t F, int mode, int bare,
+                          const float* frame_window, const float* offset, const float* scale, float* out, int64_t ld_out,
+                          void* stream) {
+  return phase_scan_impl(X_complex, phase, B, T, F, mode, bare, frame_window, offset, scale, out, ld_out, stream);
+}
+
+int at_phase_integrate(const float* y, int64_t B, int64_t T, int64_t F, int method, int rescale, const float* offset,
+                       const float* scale, float* out, void* stream) {
+  return phase_integrate_impl<false>(y, F, B, T, F, method, rescale, offset, scale, nullptr, out, stream);
+}
+
+int at_phase_integrate_polar(const float* y, int64_t ld_y, int64_t B, int64_t T, int64_t F, int method, const float* offset,
+                             const float* scale, const float* mag, float* out_complex, void* stream) {
+  return phase_integrate_impl<true>(y, ld_y, B, T, F, method, 1, offset, scale, mag, out_complex, stream);
 }
 
 int at_polar_to_complex(const float* mag, const float* phase, int64_t n, float* out_complex, void* stream) {

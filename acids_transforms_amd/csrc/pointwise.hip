@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "fastmath.h"
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/acids_hip.h"
 
@@ -101,6 +102,43 @@ __global__ void affine_kernel(const float* __restrict__ x, long long n, const fl
   const float off = *offset, sc = *scale;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     out[i] = inverse ? __fadd_rn(__fmul_rn(x[i], sc), off) : (x[i] - off) / sc;
+}
+
+// Cartesian (reference spectral_repr.py:403-428): normalise(x.real) and normalise(x.imag) stacked on dim -2, and back.
+// One pass over the spectrum either way: (rows, F) complex64 <-> (rows, 2, F) float32.  A null offset: no Normalize
+// on that half.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void cartesian_pack_kernel(const float2* __restrict__ x, long long rows, int F,
+                                                             const float* re_off, const float* re_sc, const float* im_off,
+                                                             const float* im_sc, float* __restrict__ out) {
+  const float ro = re_off ? *re_off : 0.f, rs = re_off ? *re_sc : 1.f;
+  const float io = im_off ? *im_off : 0.f, is = im_off ? *im_sc : 1.f;
+  using Idx = typename std::conditional<WIDE, unsigned long long, unsigned>::type;
+  const Idx total = (Idx)rows * (Idx)F;
+  for (Idx i = (Idx)blockIdx.x * 256 + threadIdx.x; i < total; i += (Idx)gridDim.x * 256) {
+    const Idx r = i / (Idx)F, f = i - r * (Idx)F;
+    const float2 v = x[i];
+    float* dst = out + (2 * (unsigned long long)r) * F + f;
+    dst[0] = re_off ? (v.x - ro) / rs : v.x;
+    dst[F] = im_off ? (v.y - io) / is : v.y;
+  }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void cartesian_unpack_kernel(const float* __restrict__ y, long long rows, int F,
+                                                               const float* re_off, const float* re_sc,
+                                                               const float* im_off, const float* im_sc,
+                                                               float2* __restrict__ out) {
+  const float ro = re_off ? *re_off : 0.f, rs = re_off ? *re_sc : 1.f;
+  const float io = im_off ? *im_off : 0.f, is = im_off ? *im_sc : 1.f;
+  using Idx = typename std::conditional<WIDE, unsigned long long, unsigned>::type;
+  const Idx total = (Idx)rows * (Idx)F;
+  for (Idx i = (Idx)blockIdx.x * 256 + threadIdx.x; i < total; i += (Idx)gridDim.x * 256) {
+    const Idx r = i / (Idx)F, f = i - r * (Idx)F;
+    const float* src = y + (2 * (unsigned long long)r) * F + f;
+    const float re = src[0], im = src[F];
+    out[i] = make_float2(re_off ? __fadd_rn(__fmul_rn(re, rs), ro) : re, im_off ? __fadd_rn(__fmul_rn(im, is), io) : im);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -267,6 +305,40 @@ int at_affine(const float* x, int64_t n, const float* offset, const float* scale
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
+
+int at_cartesian_pack(const float* x_complex, int64_t rows, int F, const float* re_offset, const float* re_scale,
+                      const float* im_offset, const float* im_scale, float* stacked, void* stream) {
+  if (rows < 0 || F <= 0) return AT_EINVAL;
+  if (rows == 0) return AT_OK;
+  if (!x_complex || !stacked) return AT_EINVAL;
+  if ((re_offset == nullptr) != (re_scale == nullptr) || (im_offset == nullptr) != (im_scale == nullptr)) return AT_EINVAL;
+  const long long n = (long long)rows * F;
+  const unsigned grid = grid_for(n, 256) * 4;      // grid_for caps at 8 blocks per CU: one element per thread and trip here
+  if (n < (1LL << 32))
+    hipLaunchKernelGGL(cartesian_pack_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float2*)x_complex,
+                       (long long)rows, F, re_offset, re_scale, im_offset, im_scale, stacked);
+  else
+    hipLaunchKernelGGL(cartesian_pack_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float2*)x_complex,
+                       (long long)rows, F, re_offset, re_scale, im_offset, im_scale, stacked);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
+int at_cartesian_unpack(const float* stacked, int64_t rows, int F, const float* re_offset, const float* re_scale,
+                        const float* im_offset, const float* im_scale, float* out_complex, void* stream) {
+  if (rows < 0 || F <= 0) return AT_EINVAL;
+  if (rows == 0) return AT_OK;
+  if (!stacked || !out_complex) return AT_EINVAL;
+  if ((re_offset == nullptr) != (re_scale == nullptr) || (im_offset == nullptr) != (im_scale == nullptr)) return AT_EINVAL;
+  const long long n = (long long)rows * F;
+  const unsigned grid = grid_for(n, 256) * 4;
+  if (n < (1LL << 32))
+    hipLaunchKernelGGL(cartesian_unpack_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, stacked, (long long)rows,
+                       F, re_offset, re_scale, im_offset, im_scale, (float2*)out_complex);
+  else
+    hipLaunchKernelGGL(cartesian_unpack_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, stacked, (long long)rows,
+                       F, re_offset, re_scale, im_offset, im_scale, (float2*)out_complex);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
 
 int at_oadd_forward(const float* x, const float* hist_in_or_null, int S, int64_t C, int keep, int64_t buf_len,
                     float* buf, float* hist_out, void* stream) {

@@ -209,7 +209,7 @@ struct OlaParams {
 
 // gather-form overlap-add with torch.istft's envelope division and centre trim
 __global__ void ola_gather_kernel(OlaParams p) {
-  const long long out_len = (long long)p.hop * (p.T - 1);
+  const long long out_len = (long long)p.hop * (p.T - 1) + (p.n_fft & 1);   // torch.istft trims n_fft / 2 (floor) at both ends
   const long long total = p.B * out_len;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -297,7 +297,7 @@ int launch_irfft_generic(const float2* X, const float* mag, const float* phase, 
 
 int launch_ola_gather(const float* frames, long long B, long long T, int n_fft, int hop, const float* window,
                       float* y, hipStream_t stream) {
-  long long total = B * (long long)hop * (T - 1);
+  long long total = B * ((long long)hop * (T - 1) + (n_fft & 1));
   if (total <= 0) return 0;
   OlaParams p = {frames, window, y, B, T, n_fft, hop};
   const bool vec4 = (hop % 4 == 0) && (n_fft % 8 == 0) && (((uintptr_t)frames) & 15) == 0 && (((uintptr_t)window) & 15) == 0 &&

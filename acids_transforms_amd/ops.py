@@ -29,7 +29,7 @@ def stft_forward(x, window, n_fft, hop, center=True, want_phase=False, T=None, c
         L = x.shape[1]
         clip_stride = L
     if T is None:
-        T = 1 + L // hop if center else None
+        T = 1 + (L - (n_fft & 1)) // hop if center else None      # torch.stft pads n_fft // 2 (floor) on both sides
     F = n_fft // 2 + 1
     out = torch.empty((B, T, F), dtype=torch.complex64, device=x.device)
     phase = torch.empty((B, T, F), dtype=torch.float32, device=x.device) if want_phase else None
@@ -46,7 +46,7 @@ def istft_envelope_table(inv_window, n_fft, hop):
 
 
 def istft(X, inv_window, n_fft, hop, env16=None, mag=None, phase=None):
-    """(B, T, F) complex64 -- or mag & phase float32 -- -> (B, hop*(T-1)) float32."""
+    """(B, T, F) complex64 -- or mag & phase float32 -- -> (B, hop*(T-1) + (n_fft & 1)) float32 (torch.istft's length)."""
     src = X if X is not None else mag
     require_device(src, inv_window)
     if X is not None:
@@ -59,7 +59,8 @@ def istft(X, inv_window, n_fft, hop, env16=None, mag=None, phase=None):
             phase = phase.expand_as(mag).contiguous()
     B, T, F = src.shape
     assert F == n_fft // 2 + 1, "last dim must be n_fft/2+1"
-    y = torch.empty((B, hop * max(T - 1, 0)), dtype=torch.float32, device=src.device)
+    # torch.istft trims n_fft // 2 at both ends of the n_fft + hop (T - 1) overlap-added samples
+    y = torch.empty((B, hop * (T - 1) + (n_fft & 1) if T > 0 else 0), dtype=torch.float32, device=src.device)
     if env16 is None and n_fft in (512, 1024, 2048) and hop in (n_fft // 8, n_fft // 4, n_fft // 2):
         env16 = istft_envelope_table(inv_window, n_fft, hop)      # the fused kernel's table (modules cache theirs)
     wsb = lib().at_istft_workspace_bytes(B, T, n_fft, hop)
@@ -590,6 +591,67 @@ def phase_integrate(y, method, offset=None, scale=None, rescale=True):
     out = torch.empty_like(y)
     check(lib().at_phase_integrate(ptr(y), B, T, F, SCAN_MODES[method], int(rescale), ptr(offset), ptr(scale), ptr(out),
                                    stream_ptr()), "at_phase_integrate")
+    return out
+
+
+def polarif_forward(x, band, contrast, mag_offset, mag_scale, eps, method, frame_window=None, if_offset=None,
+                    if_scale=None):
+    """PolarIF.forward written straight into the stacked tensor: x (..., T, F) complex64 -> (..., T, 2, F) with
+    [..., 0, :] = normalise(contrast(|x| @ bank)) (banded bank with F filters) and [..., 1, :] = normalise(IF(x))."""
+    import ctypes
+    require_device(x)
+    x = _prep_in(x)
+    B, T, F = _btf(x)
+    assert band.N == F and band.K == F and band.eligible and method in ("forward", "backward", "central")
+    out = torch.empty(x.shape[:-1] + (2, F), dtype=torch.float32, device=x.device)
+    _project_banded(x, 0, band, contrast, False, mag_offset, mag_scale, eps, out, F, 0, ld_out=2 * F)
+    if frame_window is not None:
+        frame_window = _f32c(frame_window.to(x.device))
+        assert frame_window.numel() == T
+    check(lib().at_phase_scan_strided(ptr(x), None, B, T, F, SCAN_MODES[method], 0, ptr(frame_window), ptr(if_offset),
+                                      ptr(if_scale), ctypes.c_void_p(out.data_ptr() + 4 * F), 2 * F, stream_ptr()),
+          "at_phase_scan_strided")
+    return out
+
+
+def polarif_inverse(y, inv_band, contrast, mag_offset, mag_scale, eps, method, if_offset=None, if_scale=None):
+    """PolarIF.invert reading the stacked tensor in place: y (..., T, 2, F) -> (..., T, F) complex64 =
+    Magnitude.invert(y[.., 0, :]) * exp(i * IF.invert(y[.., 1, :]))."""
+    import ctypes
+    require_device(y)
+    y = _f32c(y)
+    F = y.shape[-1]
+    T = y.shape[-3]
+    rows = y.numel() // (2 * F)
+    assert inv_band.K == F and inv_band.N == F and inv_band.eligible and method in ("forward", "backward", "central")
+    mag = torch.empty(y.shape[:-2] + (F,), dtype=torch.float32, device=y.device)
+    _project_banded(y, 2, inv_band, contrast, True, mag_offset, mag_scale, eps, mag, F, 0, rows=rows, lda=2 * F)
+    out = torch.empty(y.shape[:-2] + (F,), dtype=torch.complex64, device=y.device)
+    check(lib().at_phase_integrate_polar(ctypes.c_void_p(y.data_ptr() + 4 * F), 2 * F, rows // T, T, F, SCAN_MODES[method],
+                                         ptr(if_offset), ptr(if_scale), ptr(mag), ptr(out), stream_ptr()),
+          "at_phase_integrate_polar")
+    return out
+
+
+def cartesian_forward(x, re_offset=None, re_scale=None, im_offset=None, im_scale=None):
+    """Cartesian.forward in one pass: x (..., F) complex64 -> (..., 2, F) = [normalise(x.real), normalise(x.imag)]."""
+    require_device(x)
+    x = _prep_in(x)
+    F = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (2, F), dtype=torch.float32, device=x.device)
+    check(lib().at_cartesian_pack(ptr(x), x.numel() // F, F, ptr(re_offset), ptr(re_scale), ptr(im_offset), ptr(im_scale),
+                                  ptr(out), stream_ptr()), "at_cartesian_pack")
+    return out
+
+
+def cartesian_inverse(y, re_offset=None, re_scale=None, im_offset=None, im_scale=None):
+    """Cartesian.invert in one pass: y (..., 2, F) float32 -> (..., F) complex64."""
+    require_device(y)
+    y = _f32c(y)
+    F = y.shape[-1]
+    out = torch.empty(y.shape[:-2] + (F,), dtype=torch.complex64, device=y.device)
+    check(lib().at_cartesian_unpack(ptr(y), y.numel() // (2 * F), F, ptr(re_offset), ptr(re_scale), ptr(im_offset),
+                                    ptr(im_scale), ptr(out), stream_ptr()), "at_cartesian_unpack")
     return out
 
 

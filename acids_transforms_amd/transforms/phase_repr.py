@@ -288,7 +288,22 @@ class Cartesian(SpectralRepresentation):
                  keep_nyquist: bool = True):
         super().__init__(sr, Real, Imaginary, real_args, imag_args, stack=stack, keep_nyquist=keep_nyquist)
 
+    def _one_pass_ok(self, x, stacked: bool) -> bool:
+        """Both halves as they come (Real / Imaginary with or without Normalize), stacked on dim -2: one kernel reads
+        the spectrum once and writes the stacked tensor (and the reverse)."""
+        if not (type(self.magnitude) is Real and type(self.phase) is Imaginary and self.stack == -2
+                and self.keep_nyquist and isinstance(x, torch.Tensor) and x.is_cuda):
+            return False
+        return (x.dtype == torch.float32 and x.ndim >= 2 and x.shape[-2] == 2) if stacked else (x.is_complex() and x.ndim >= 1)
+
+    def forward(self, x: torch.Tensor) -> SpectralRepresentationType:
+        if self._one_pass_ok(x, False):
+            return ops.cartesian_forward(x, *self.magnitude._affine(x), *self.phase._affine(x))
+        return super().forward(x)
+
     def invert(self, x, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        if self._one_pass_ok(x, True):
+            return ops.cartesian_inverse(x, *self.magnitude._affine(x), *self.phase._affine(x))
         real, imag = self._split(x)
         return torch.complex(self.magnitude.invert(real).contiguous(), self.phase.invert(imag).contiguous())
 
@@ -309,3 +324,39 @@ class PolarIF(SpectralRepresentation):
     def __init__(self, sr: int = 44100, magnitude_args={"mode": "bipolar"}, phase_args={"mode": "bipolar"}, stack=-2,
                  keep_nyquist: bool = True):
         super().__init__(sr, Magnitude, IF, magnitude_args, phase_args, stack=stack, keep_nyquist=keep_nyquist)
+
+    def _in_place_parts(self, F: int, inverse: bool):
+        """Banded bank of the magnitude half when both halves can work inside the stacked tensor: Magnitude over a
+        banded bank of F filters, IF with one of the three methods, stacked on dim -2."""
+        mag, ph = self.magnitude, self.phase
+        if not (type(mag) is Magnitude and type(ph) is IF and self.stack == -2 and mag.mel and mag.keep_nyquist
+                and ph.keep_nyquist and ph.method in ("forward", "backward", "central")):
+            return None
+        band = mag._band_of("inverse_mel_bank" if inverse else "mel_bank")
+        if band is None or band.K != F or band.N != F:
+            return None
+        return band
+
+    def forward(self, x: torch.Tensor) -> SpectralRepresentationType:
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.is_complex() and x.ndim >= 2 \
+                and not (self.phase.method == "central" and x.size(-2) == 1):
+            band = self._in_place_parts(x.shape[-1], False)
+            if band is not None:
+                mag, ph = self.magnitude, self.phase
+                mag._follow(x)
+                m_off, m_sc = mag._affine()
+                p_off, p_sc = ph._affine(x)
+                window = ph._get_weighted_window(x) if ph.weighted else None
+                return ops.polarif_forward(x, band, mag.contrast_mode, m_off, m_sc, mag._eps, ph.method, window, p_off, p_sc)
+        return super().forward(x)
+
+    def invert(self, x, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4) -> torch.Tensor:
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.ndim >= 3 and x.shape[-2] == 2:
+            band = self._in_place_parts(x.shape[-1], True)
+            if band is not None:
+                mag, ph = self.magnitude, self.phase
+                mag._follow(x)
+                m_off, m_sc = mag._affine()
+                p_off, p_sc = ph._affine(x)
+                return ops.polarif_inverse(x, band, mag.contrast_mode, m_off, m_sc, mag._eps, ph.method, p_off, p_sc)
+        return super().invert(x, inversion_mode, tolerance)

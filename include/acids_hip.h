@@ -100,7 +100,9 @@ size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop);
  *     replaces stft.py:120-128, dgt.py:86-93 (complex input: X != NULL), and
  *     `x * exp(1j*phase)` + istft, stft.py:157-161 / dgt.py:152-154
  *     (polar input: X == NULL, mag and phase given).
- * y: (B, hop*(T-1)).  env16 (at_istft_envelope_table) is required for n_fft=1024 with hop=128, 256 or 512 and for
+ * y: (B, hop*(T-1) + (n_fft & 1)) -- torch.istft trims n_fft/2 (floor) at both ends.  Any n_fft in [2, 16384] (odd
+ * sizes below 8192): powers of two on the kernels named below, everything else on the mixed-radix kernels of
+ * stft_mixed.hip (the same holds for at_stft_forward and at_irfft_frames).  env16 (at_istft_envelope_table) is required for n_fft=1024 with hop=128, 256 or 512 and for
  * n_fft=2048 / 512 with hop = n_fft/8, n_fft/4 or n_fft/2 -- the fused kernels, for which at_istft_workspace_bytes
  * is 0 -- and may be NULL otherwise.  n_fft = 512 and 2048 run on the register FFT core (stft512.hip, stft2048.hip), the other sizes on
  * the generic LDS kernel. */
@@ -210,6 +212,14 @@ int at_rt_update_buffers(const float *mag, const float *phase, int S, int n, int
  * and hgi_phase_buffer of dgt.py:336. */
 int at_angle(const float *x_complex, int64_t n, float *out, void *stream);
 
+/* Cartesian.forward / invert (spectral_repr.py:403-428) in one pass: (rows, F) complex64 <-> (rows, 2, F) float32
+ * with [r, 0, :] = (x.real - re_offset) / re_scale and [r, 1, :] = (x.imag - im_offset) / im_scale (Normalize,
+ * norm.py:40-44; a NULL offset/scale pair: that half is not normalised); unpack applies y * scale + offset. */
+int at_cartesian_pack(const float *x_complex, int64_t rows, int F, const float *re_offset, const float *re_scale,
+                      const float *im_offset, const float *im_scale, float *stacked, void *stream);
+int at_cartesian_unpack(const float *stacked, int64_t rows, int F, const float *re_offset, const float *re_scale,
+                        const float *im_offset, const float *im_scale, float *out_complex, void *stream);
+
 /* ---- Griffin-Lim building blocks (STFT's default inversion mode, stft.py:37,174-178) ---- */
 /* One phase update of torchaudio.functional.griffinlim:  a = rebuilt - m*tprev (tprev may be NULL);
  * X = mag * a / (|a| + 1e-16), with m = momentum / (1 + momentum).  n complex elements. */
@@ -295,6 +305,17 @@ int at_phase_scan(const float *X_complex, const float *phase, int64_t B, int64_t
  * and integrate along t.  out != y. */
 int at_phase_integrate(const float *y, int64_t B, int64_t T, int64_t F, int method, int rescale, const float *offset,
                        const float *scale, float *out, void *stream);
+
+/* The same scan writing frames ld_out >= F floats apart: the phase half of a stacked (.., T, 2, F) representation is
+ * filled in place (out = stacked + F, ld_out = 2 F) -- PolarIF.forward without the torch.stack copy. */
+int at_phase_scan_strided(const float *X_complex, const float *phase, int64_t B, int64_t T, int64_t F, int mode, int bare,
+                          const float *frame_window, const float *offset, const float *scale, float *out, int64_t ld_out,
+                          void *stream);
+/* IF.invert fused with SpectralRepresentation.invert's mag * exp(i * phase) (spectral_repr.py:360-373, 449-451): y has
+ * frames ld_y >= F floats apart (the phase half of a stacked tensor: y = stacked + F, ld_y = 2 F), mag is (B, T, F)
+ * contiguous, out_complex (B, T, F) complex64. */
+int at_phase_integrate_polar(const float *y, int64_t ld_y, int64_t B, int64_t T, int64_t F, int method, const float *offset,
+                             const float *scale, const float *mag, float *out_complex, void *stream);
 
 /* mag * exp(i * phase) -> complex64 (SpectralRepresentation.invert, spectral_repr.py:449-451). */
 int at_polar_to_complex(const float *mag, const float *phase, int64_t n, float *out_complex, void *stream);

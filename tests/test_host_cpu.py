@@ -108,7 +108,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(L, name), "missing export: " + name
     assert sorted(_lib.exported_symbols()) == declared            # the Python binding covers the whole ABI
     lib = _lib.lib()
-    assert lib.at_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.at_abi_version() == _lib.ABI_VERSION == 3
     assert lib.at_error_string(-2).decode() == "unsupported configuration"
     assert lib.at_istft_workspace_bytes(4, 10, 1024, 256) == 0
     assert lib.at_istft_workspace_bytes(4, 10, 512, 128) == 0 and lib.at_istft_workspace_bytes(4, 10, 2048, 512) == 0

@@ -11,6 +11,7 @@ import torch
 
 import acids_transforms_amd as A
 from acids_transforms_amd import ops
+from conftest import rel_max
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -72,6 +73,28 @@ def test_offline_batch_matches_per_clip_oracle(dev):
         assert int(npops[b]) == k
         assert np.array_equal(cpu(order[b][:k]), r["order"][:, 0] * F + r["order"][:, 1])
         assert np.all(np.abs(cpu(ph[b]) - r["phase"]) <= phase_tol(r["phase"]))
+
+
+@pytest.mark.parametrize("n,h", [(400, 100), (441, 110), (1000, 250), (254, 64)])
+def test_offline_sizes_that_are_not_powers_of_two(dev, n, h):
+    """DGT(n_fft not a power of two): the heap integration follows the oracle pop for pop (the phase-gradient
+    constants depend on n_fft and hop only), and `invert(|X|, "pghi")` runs end to end on the mixed-radix kernels."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(2, 12 * n, generator=g) * 0.1
+    d = A.DGT(n_fft=n, hop_length=h).to(dev)
+    mags = d(x.to(dev)).abs()
+    F = n // 2 + 1
+    assert mags.shape[-1] == F
+    ph, npops, order = ops.pghi_offline(mags, float(d.gamma), n, h, float(d.tolerance), float(d.eps), debug=True)
+    for b in range(2):
+        r = O.pghi_offline(mags[b].cpu(), n, h, want_order=True)
+        k = len(r["order"])
+        assert int(npops[b]) == k
+        assert np.array_equal(cpu(order[b][:k]), r["order"][:, 0] * F + r["order"][:, 1])
+        assert np.all(np.abs(cpu(ph[b]) - r["phase"]) <= phase_tol(r["phase"]))
+    y = d.invert(mags, inversion_mode="pghi")
+    yr = O.polar_istft(mags.cpu(), torch.from_numpy(cpu(ph)), d.inv_window[:n].cpu(), n, h)
+    assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < 1e-4
 
 
 def test_offline_invert_end_to_end_golden(golden, dev):

@@ -255,6 +255,47 @@ def test_polar_one_pass_equals_parts(dev):
         p2(Xd)
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 21, 513), (2, 1, 513), (1, 2, 129), (4, 33, 1025), (7, 257)])
+def test_cartesian_and_polarif_work_inside_the_stacked_tensor(dev, shape):
+    """Cartesian is one pack / unpack kernel, PolarIF's halves are written into / read from the stacked tensor in place
+    (banded magnitude with a row stride, IF scan with a row stride, integration fused with mag * exp(i phase)): the
+    same values as the parts run on their own and torch.stack / polar_to_complex."""
+    gen = torch.Generator().manual_seed(sum(shape))
+    X = (torch.randn(*shape, generator=gen) * torch.exp(2j * np.pi * torch.rand(*shape, generator=gen))).to(torch.complex64)
+    Xd = X.to(dev)
+    F = shape[-1]
+    for kw in ({}, {"real_args": {"mode": None}}, {"imag_args": {"mode": "unipolar"}, "real_args": {"mode": "bipolar"}}):
+        c = A.Cartesian(**kw).to(dev)
+        c.scale_data(Xd)
+        assert c._one_pass_ok(Xd, False)
+        y = c(Xd)
+        want = torch.stack([c.magnitude(Xd), c.phase(Xd)], -2)
+        assert y.shape == shape[:-1] + (2, F) and torch.equal(y, want)
+        back = c.invert(y)
+        assert back.dtype == torch.complex64
+        assert torch.equal(back, torch.complex(c.magnitude.invert(y[..., 0, :]).contiguous(), c.phase.invert(y[..., 1, :]).contiguous()))
+        assert rel_max(cpu(back).numpy(), X.numpy()) < TOL
+    if len(shape) < 3:
+        return
+    for method in ("forward", "backward", "central"):
+        for weighted in (False, True):
+            if shape[-2] == 1 and (method == "central" or weighted):     # one frame: the weight divides by N^2 - 1 = 0
+                continue
+            p = A.PolarIF(magnitude_args={"mode": "bipolar", "n_fft": 2 * (F - 1)},
+                          phase_args={"mode": "gaussian", "method": method, "weighted": weighted}).to(dev)
+            p.scale_data(Xd)
+            assert p._in_place_parts(F, False) is not None and p._in_place_parts(F, True) is not None
+            y = p(Xd)
+            assert y.shape == shape[:-1] + (2, F)
+            assert torch.equal(y[..., 0, :], p.magnitude(Xd)) and torch.equal(y[..., 1, :], p.phase(Xd)), (method, weighted)
+            back = p.invert(y)
+            parts = ops.polar_to_complex(p.magnitude.invert(y[..., 0, :]), p.phase.invert(y[..., 1, :]))
+            assert back.dtype == torch.complex64 and torch.equal(back, parts), (method, weighted)
+    # a variant that does not qualify takes the generic path
+    p2 = A.PolarIF(stack=None).to(dev)
+    assert p2._in_place_parts(F, False) is None
+
+
 def test_compose_stft_polar_is_one_kernel(dev):
     """ComposeAudioTransform(STFT|DGT + Polar) with default parts: framing, FFT, banded magnitude and phase in a
     single kernel that never writes the complex spectrum.  Same values as stage by stage; the STFT stage's

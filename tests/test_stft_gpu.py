@@ -325,6 +325,29 @@ def test_every_power_of_two_size(dev, n):
             assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL, (hop, cls.__name__)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [6, 12, 77, 254, 400, 441, 1000, 1200, 1536, 1920, 2000, 2401, 6000, 8191, 12000])
+def test_sizes_that_are_not_powers_of_two(dev, n):
+    """torch.stft takes any n_fft (stft.py:67-75), so do the mixed-radix kernels: radix 4 / 2 / 3 / 5 / 7 stages,
+    a direct DFT for other prime factors (254 = 2 x 127, 8191 prime), odd sizes at full length (77, 441, 2401, 8191),
+    sizes whose twiddle table does not fit LDS (12000).  STFT and DGT, forward and inverse, against the oracle."""
+    from acids_transforms_amd import ops
+    hops = (max(1, n // 4), max(1, n // 3)) if n < 8000 else (n // 4,)
+    for hop in hops:
+        torch.manual_seed(n + hop)
+        x = torch.randn(2, max(3 * n, 2000)) * 0.1
+        for cls in (A.STFT, A.DGT):
+            t = cls(n_fft=n, hop_length=hop).to(dev)
+            X = t(x.to(dev))
+            Xr = O.stft_forward(x, t.window[:n].cpu(), n, hop)
+            assert X.shape == Xr.shape and rel_max(cpu(X), Xr.numpy()) < TOL, (hop, cls.__name__)
+            y, yr = t.invert(X), O.istft(Xr, t.inv_window[:n].cpu(), n, hop)
+            assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL, (hop, cls.__name__)
+            # polar input of the inverse (magnitude + phase) through the same kernels
+            yp = ops.istft(None, t.inv_window[:n], n, hop, mag=X.abs(), phase=X.angle())
+            assert rel_max(cpu(yp), yr.numpy()) < 2 * TOL, (hop, cls.__name__)
+
+
 def test_bench_step_at_full_batch_vs_oracle(dev):
     """What bench.py times, at its size: B = 1024 clips x 4 s through the fused STFT+mel forward and the ISTFT; the
     launchers cut 1024 clips into runs by occupancy, so clips from both ends and the middle are checked against the
