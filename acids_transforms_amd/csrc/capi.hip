@@ -36,6 +36,13 @@ int launch_irfft2048_frames(const float2*, const float*, const float*, long long
                             const float2*, float*, hipStream_t);
 int launch_istft2048_ola(const float2*, const float*, const float*, long long, long long, int, const float*,
                          const float*, const float2*, const float2*, float*, hipStream_t);
+// stft4096.hip
+int launch_stft4096_fwd(const float*, long long, long long, long long, long long, int, int, const float*, const float2*,
+                        const float2*, float2*, float*, hipStream_t);
+int launch_istft4096_ola(const float2*, const float*, const float*, long long, long long, int, const float*, const float*,
+                         const float2*, const float2*, float*, hipStream_t);
+int launch_irfft4096_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
+                            const float2*, float*, hipStream_t);
 // stft_small.hip (n_fft 256 / 128: four / eight frames per wave-level FFT)
 int launch_stft_small_fwd(int, const float*, long long, long long, long long, long long, int, int, const float*, const float2*,
                           const float2*, float2*, float*, hipStream_t);
@@ -136,7 +143,17 @@ int at_init(int device) {
   if (rc == AT_OK) {
     // [0, 1024): W2048^k; [1024, 1280): W512^k; [1280, 1664): W512^(r k), r = 1..3, k < 128 (n_fft 256);
     // [1664, 2112): W512^(r k), r = 1..7, k < 64 (n_fft 128)
-    std::vector<float2> t2(1024 + 256 + 384 + 448);
+    // [2112, 4160): W4096^k, k < 2048; [4160, 5696): W2048^(r k), r = 1..3, k < 512 (n_fft 4096, stft4096.hip)
+    std::vector<float2> t2(1024 + 256 + 384 + 448 + 2048 + 1536);
+    for (int k = 0; k < 2048; ++k) {
+      const double a = -two_pi * (double)k / 4096.0;
+      t2[2112 + k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    for (int r = 1; r < 4; ++r)
+      for (int k = 0; k < 512; ++k) {
+        const double a = -two_pi * (double)(r * k) / 2048.0;
+        t2[4160 + (r - 1) * 512 + k] = make_float2((float)cos(a), (float)sin(a));
+      }
     for (int r = 1; r < 4; ++r)
       for (int k = 0; k < 128; ++k) {
         const double a = -two_pi * (double)(r * k) / 512.0;
@@ -188,6 +205,12 @@ int at_stft_forward(const float* x, int64_t B, int64_t L, int64_t clip_stride, i
     const float2* tw2k = tw2048_for_current_device();
     if (!tw || !tw2k) return AT_ENOTINIT;
     return launch_stft2048_fwd(x, B, L, clip_stride, T, hop, center, window, tw, tw2k, (float2*)out_complex, phase, s);
+  }
+  if (n_fft == 4096 && (((uintptr_t)window) & 15) == 0) {      // four 512-point register FFTs + a radix-4 stage per frame
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_stft4096_fwd(x, B, L, clip_stride, T, hop, center, window, tw, tw2k + 2112, (float2*)out_complex, phase, s);
   }
   if ((n_fft == 256 || n_fft == 128) && (((uintptr_t)window) & 7) == 0) {     // four / eight frames per register FFT
     const float2* tw = twiddles_for_current_device();
@@ -290,6 +313,7 @@ size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop) {
   if (n_fft == 1024 && (hop == 128 || hop == 256 || hop == 512)) return 0;   // with the envelope table; see at_istft
   if (n_fft == 2048 && (hop == 256 || hop == 512 || hop == 1024)) return 0;  // likewise (stft2048.hip)
   if (n_fft == 512 && (hop == 64 || hop == 128 || hop == 256)) return 0;      // likewise (stft512.hip)
+  if (n_fft == 4096 && (hop == 512 || hop == 1024 || hop == 2048)) return 0;  // likewise (stft4096.hip)
   return (size_t)B * (size_t)T * (size_t)n_fft * sizeof(float);
 }
 
@@ -313,6 +337,13 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
     if (!tw || !tw2k) return AT_ENOTINIT;
     return launch_istft2048_ola((const float2*)X_complex, mag, phase, B, T, hop, inv_window, env16, tw, tw2k, y, s);
   }
+  if (n_fft == 4096 && (hop == 512 || hop == 1024 || hop == 2048) && env16 && (((uintptr_t)inv_window) & 15) == 0 &&
+      (((uintptr_t)env16) & 15) == 0 && (((uintptr_t)y) & 15) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_istft4096_ola((const float2*)X_complex, mag, phase, B, T, hop, inv_window, env16, tw, tw2k + 2112, y, s);
+  }
   if (n_fft == 512 && (hop == 64 || hop == 128 || hop == 256) && env16 && (((uintptr_t)inv_window) & 7) == 0 &&
       (((uintptr_t)env16) & 7) == 0 && (((uintptr_t)y) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();
@@ -328,6 +359,11 @@ int at_istft(const float* X_complex, const float* mag, const float* phase, int64
     const float2* tw2k = tw2048_for_current_device();
     if (!tw || !tw2k) return AT_ENOTINIT;
     rc = launch_irfft2048_frames((const float2*)X_complex, mag, phase, B * T, inv_window, tw, tw2k, (float*)workspace, s);
+  } else if (n_fft == 4096 && (((uintptr_t)inv_window) & 15) == 0 && (((uintptr_t)workspace) & 15) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    rc = launch_irfft4096_frames((const float2*)X_complex, mag, phase, B * T, inv_window, tw, tw2k + 2112, (float*)workspace, s);
   } else if ((n_fft == 256 || n_fft == 128) && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)workspace) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();
     const float2* tw2k = tw2048_for_current_device();
@@ -382,6 +418,12 @@ int at_irfft_frames(const float* X_complex, const float* mag, const float* phase
     const float2* tw2k = tw2048_for_current_device();
     if (!tw || !tw2k) return AT_ENOTINIT;
     return launch_irfft2048_frames((const float2*)X_complex, mag, phase, nframes, inv_window, tw, tw2k, frames, s);
+  }
+  if (n_fft == 4096 && (((uintptr_t)inv_window) & 15) == 0 && (((uintptr_t)frames) & 15) == 0) {
+    const float2* tw = twiddles_for_current_device();
+    const float2* tw2k = tw2048_for_current_device();
+    if (!tw || !tw2k) return AT_ENOTINIT;
+    return launch_irfft4096_frames((const float2*)X_complex, mag, phase, nframes, inv_window, tw, tw2k + 2112, frames, s);
   }
   if ((n_fft == 256 || n_fft == 128) && (((uintptr_t)inv_window) & 7) == 0 && (((uintptr_t)frames) & 7) == 0) {
     const float2* tw = twiddles_for_current_device();

@@ -61,7 +61,7 @@ def istft(X, inv_window, n_fft, hop, env16=None, mag=None, phase=None):
     assert F == n_fft // 2 + 1, "last dim must be n_fft/2+1"
     # torch.istft trims n_fft // 2 at both ends of the n_fft + hop (T - 1) overlap-added samples
     y = torch.empty((B, hop * (T - 1) + (n_fft & 1) if T > 0 else 0), dtype=torch.float32, device=src.device)
-    if env16 is None and n_fft in (512, 1024, 2048) and hop in (n_fft // 8, n_fft // 4, n_fft // 2):
+    if env16 is None and n_fft in (512, 1024, 2048, 4096) and hop in (n_fft // 8, n_fft // 4, n_fft // 2):
         env16 = istft_envelope_table(inv_window, n_fft, hop)      # the fused kernel's table (modules cache theirs)
     wsb = lib().at_istft_workspace_bytes(B, T, n_fft, hop)
     ws = torch.empty((wsb // 4,), dtype=torch.float32, device=src.device) if wsb else None

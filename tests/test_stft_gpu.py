@@ -377,9 +377,10 @@ def test_bench_step_at_full_batch_vs_oracle(dev):
     assert rel_max(cpu(mag(X[1000:1008])), cpu(feat[1000:1008])) < TOL
 
 
-@pytest.mark.parametrize("n", [128, 256, 512, 2048])
+@pytest.mark.parametrize("n", [128, 256, 512, 2048, 4096])
 def test_register_core_sizes_512_and_2048(dev, n):
-    """n_fft = 128 / 256 / 512 (eight / four / two frames per wave-level FFT) and 2048 (two FFTs + a radix-2 stage per frame) on the register core:
+    """n_fft = 128 / 256 / 512 (eight / four / two frames per wave-level FFT), 2048 (two FFTs + a radix-2 stage per
+    frame) and 4096 (four FFTs + a radix-4 stage) on the register core:
     forward, complex and polar inverse, phase side output, realtime frames, odd frame counts, unaligned clip
     lengths and hops, STFT and DGT windows -- against the oracle."""
     from acids_transforms_amd import ops
