@@ -652,9 +652,10 @@ def main():
         return res
 
     def extra_other_sizes():
-        # n_fft 512 / 2048 (hop n_fft / 4) on the register FFT core: two frames per wave FFT / two FFTs per frame
+        # n_fft 512 / 2048 / 4096 (hop n_fft / 4) on the register FFT core: two frames per wave FFT / two / four FFTs per
+        # frame; n_fft 400 (hop 160) on the mixed-radix kernels
         res = {}
-        for n in (512, 2048):
+        for n in (512, 2048, 4096):
             st = A.STFT(sr=SR, n_fft=n, hop_length=n // 4).to(dev)
             Xh = st(x)
             f_ms = timed_ms(lambda: st(x), 3, 1)
@@ -665,6 +666,11 @@ def main():
                                    "forward_frac_of_8TBps": round(frames * bytes_per_frame / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "inverse_frac_of_8TBps": round(frames * bytes_per_frame / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del Xh
+        st = A.STFT(sr=SR, n_fft=400, hop_length=160).to(dev)
+        Xh = st(x)
+        res["n_fft_400_hop_160"] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(timed_ms(lambda: st(x), 3, 1), 4),
+                                    "inverse_ms": round(timed_ms(lambda: st.invert(Xh), 3, 1), 4)}
+        del Xh
         return res
 
     def extra_griffin_lim():

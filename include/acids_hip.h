@@ -102,10 +102,11 @@ size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop);
  *     (polar input: X == NULL, mag and phase given).
  * y: (B, hop*(T-1) + (n_fft & 1)) -- torch.istft trims n_fft/2 (floor) at both ends.  Any n_fft in [2, 16384] (odd
  * sizes below 8192): powers of two on the kernels named below, everything else on the mixed-radix kernels of
- * stft_mixed.hip (the same holds for at_stft_forward and at_irfft_frames).  env16 (at_istft_envelope_table) is required for n_fft=1024 with hop=128, 256 or 512 and for
- * n_fft=2048 / 512 with hop = n_fft/8, n_fft/4 or n_fft/2 -- the fused kernels, for which at_istft_workspace_bytes
- * is 0 -- and may be NULL otherwise.  n_fft = 512 and 2048 run on the register FFT core (stft512.hip, stft2048.hip), the other sizes on
- * the generic LDS kernel. */
+ * stft_mixed.hip (the same holds for at_stft_forward and at_irfft_frames).  env16 (at_istft_envelope_table) is
+ * required for n_fft = 1024, 512, 2048 and 4096 with hop = n_fft/8, n_fft/4 or n_fft/2 -- the fused kernels, for which
+ * at_istft_workspace_bytes is 0 -- and may be NULL otherwise.  n_fft = 128, 256, 512, 2048 and 4096 run on the
+ * register FFT core (stft_small.hip, stft512.hip, stft2048.hip, stft4096.hip), the other powers of two on the generic
+ * LDS kernel. */
 int at_istft(const float *X_complex, const float *mag, const float *phase, int64_t B, int64_t T, int n_fft, int hop,
              const float *inv_window, const float *env16, float *y, void *workspace, size_t workspace_bytes,
              void *stream);
