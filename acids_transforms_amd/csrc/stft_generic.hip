@@ -1,6 +1,7 @@
 // stft_generic.hip -- the same transforms as stft1024.hip for any power-of-two
 // n_fft in [8, 16384] and any hop (the reference accepts arbitrary sizes:
-// transforms/stft.py:67-75).  One workgroup per frame, radix-2 Stockham in LDS.
+// transforms/stft.py:67-75).  A workgroup per frame at a time (it walks frames blockIdx.x + k gridDim.x with its twiddle
+// tables filled once), radix-4 / radix-2 Stockham in LDS.
 // Correctness path for the non-default sizes the parity tests use; the
 // n_fft = 1024 kernels in stft1024.hip are the tuned ones.
 #include <hip/hip_runtime.h>
@@ -104,47 +105,70 @@ __device__ float2* stockham(float2* a, float2* b, int M, float sign, const float
   return a;
 }
 
+// exp(sign * pi i k / M) = exp(sign * 2 pi i k / n_fft), k = 0 .. M: the twiddle of the real split, once per workgroup
+__device__ void fill_split_twiddles(float2* sp, int M, float sign) {
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+    float s, c;
+    sincospif(sign * (float)k / (float)M, &s, &c);
+    sp[k] = make_float2(c, s);
+  }
+}
+
+// A workgroup walks frames blockIdx.x, blockIdx.x + gridDim.x, ...: the twiddle tables are filled once per workgroup,
+// not once per frame (their sincospi calls used to outnumber the butterflies' own arithmetic).
 __global__ void rfft_generic_kernel(GenFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float2 sm[];
   const int Nf = p.n_fft, M = Nf / 2;
   float2* a = sm;
   float2* b = sm + M;
   float2* tw = p.use_tw ? sm + 2 * M : nullptr;
-  if (tw) fill_twiddles(tw, M, -1.0f);
-  const long long f = blockIdx.x;
-  const long long bidx = f / p.T, t = f - bidx * p.T;
-  const float* clip = p.x + bidx * p.clip_stride;
-  const long long start = t * (long long)p.hop - (p.center ? Nf / 2 : 0);
-  for (int n = threadIdx.x; n < M; n += blockDim.x) {
-    long long i0 = start + 2 * n, i1 = i0 + 1;
-    float x0, x1;
-    if (p.center) {
-      x0 = clip[g_reflect(i0, p.L)];
-      x1 = clip[g_reflect(i1, p.L)];
-    } else {
-      x0 = (i0 < p.L) ? clip[i0] : 0.f;
-      x1 = (i1 < p.L) ? clip[i1] : 0.f;
-    }
-    a[n] = make_float2(x0 * p.window[2 * n], x1 * p.window[2 * n + 1]);
+  float2* sp = p.use_tw ? tw + (3 * M / 4 + 1) : nullptr;
+  if (tw) {
+    fill_twiddles(tw, M, -1.0f);
+    fill_split_twiddles(sp, M, -1.0f);
   }
-  __syncthreads();
-  float2* Z = stockham(a, b, M, -1.0f, tw);
   const int Fb = M + 1;
-  float2* row = p.out + f * Fb;
-  float* prow = p.phase ? p.phase + f * Fb : nullptr;
-  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
-    float2 zk = Z[k & (M - 1)];
-    float2 zp = Z[(M - k) & (M - 1)];
-    zp.y = -zp.y;
-    float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y + zp.y));
-    float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y - zp.y));
-    float s, c;
-    sincospif(-2.0f * (float)k / (float)Nf, &s, &c);
-    float2 wd = g_cmul(make_float2(c, s), d);
-    float2 X = make_float2(e.x + wd.y, e.y - wd.x);
-    if (k == M) X = make_float2(Z[0].x - Z[0].y, 0.f);
-    row[k] = X;
-    if (prow) prow[k] = fast_atan2f(X.y, X.x);
+  for (long long f = blockIdx.x; f < p.B * p.T; f += gridDim.x) {
+    const long long bidx = f / p.T, t = f - bidx * p.T;
+    const float* clip = p.x + bidx * p.clip_stride;
+    const long long start = t * (long long)p.hop - (p.center ? Nf / 2 : 0);
+    for (int n = threadIdx.x; n < M; n += blockDim.x) {
+      long long i0 = start + 2 * n, i1 = i0 + 1;
+      float x0, x1;
+      if (p.center) {
+        x0 = clip[g_reflect(i0, p.L)];
+        x1 = clip[g_reflect(i1, p.L)];
+      } else {
+        x0 = (i0 < p.L) ? clip[i0] : 0.f;
+        x1 = (i1 < p.L) ? clip[i1] : 0.f;
+      }
+      a[n] = make_float2(x0 * p.window[2 * n], x1 * p.window[2 * n + 1]);
+    }
+    __syncthreads();
+    float2* Z = stockham(a, b, M, -1.0f, tw);
+    float2* row = p.out + f * Fb;
+    float* prow = p.phase ? p.phase + f * Fb : nullptr;
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+      float2 zk = Z[k & (M - 1)];
+      float2 zp = Z[(M - k) & (M - 1)];
+      zp.y = -zp.y;
+      float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y + zp.y));
+      float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y - zp.y));
+      float2 w;
+      if (sp) {
+        w = sp[k];
+      } else {
+        float s, c;
+        sincospif(-2.0f * (float)k / (float)Nf, &s, &c);
+        w = make_float2(c, s);
+      }
+      float2 wd = g_cmul(w, d);
+      float2 X = make_float2(e.x + wd.y, e.y - wd.x);
+      if (k == M) X = make_float2(Z[0].x - Z[0].y, 0.f);
+      row[k] = X;
+      if (prow) prow[k] = fast_atan2f(X.y, X.x);
+    }
+    __syncthreads();       // the next frame overwrites the buffers these reads came from
   }
 }
 
@@ -154,6 +178,7 @@ struct GenInvParams {
   const float* phase;
   const float* window;
   float* frames;  // (B*T, n_fft)
+  long long nframes;
   int n_fft;
   int use_tw;
 };
@@ -165,38 +190,50 @@ __global__ void irfft_generic_kernel(GenInvParams p) {
   float2* b = sm + M;       // M + 2 entries: until the FFT starts it stages the one-sided spectrum (Fb = M + 1)
   float2* xs = b;
   float2* tw = p.use_tw ? b + M + 2 : nullptr;
-  if (tw) fill_twiddles(tw, M, +1.0f);
-  const long long f = blockIdx.x;
-  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
-    float2 v;
-    if (p.X) {
-      v = p.X[f * Fb + k];
-    } else {
-      float s, c;
-      sincosf(p.phase[f * Fb + k], &s, &c);
-      float m = p.mag[f * Fb + k];
-      v = make_float2(m * c, m * s);
-    }
-    if (k == 0 || k == M) v.y = 0.f;
-    xs[k] = v;
+  float2* sp = p.use_tw ? tw + (3 * M / 4 + 1) : nullptr;
+  if (tw) {
+    fill_twiddles(tw, M, +1.0f);
+    fill_split_twiddles(sp, M, +1.0f);     // conj(W_N^k)
   }
-  __syncthreads();
-  for (int k = threadIdx.x; k < M; k += blockDim.x) {
-    float2 xk = xs[k];
-    float2 xp = xs[M - k];
-    xp.y = -xp.y;
-    float2 e = make_float2(xk.x + xp.x, xk.y + xp.y);
-    float s, c;
-    sincospif(2.0f * (float)k / (float)Nf, &s, &c);  // conj(W_N^k)
-    float2 d = g_cmul(make_float2(xk.x - xp.x, xk.y - xp.y), make_float2(c, s));
-    a[k] = make_float2(e.x - d.y, e.y + d.x);
-  }
-  __syncthreads();
-  float2* z = stockham(a, b, M, +1.0f, tw);
   const float sc = 1.0f / (float)Nf;
-  float2* dst = reinterpret_cast<float2*>(p.frames + f * Nf);
-  for (int n = threadIdx.x; n < M; n += blockDim.x)
-    dst[n] = make_float2((z[n].x * sc) * p.window[2 * n], (z[n].y * sc) * p.window[2 * n + 1]);
+  for (long long f = blockIdx.x; f < p.nframes; f += gridDim.x) {
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+      float2 v;
+      if (p.X) {
+        v = p.X[f * Fb + k];
+      } else {
+        float s, c;
+        sincosf(p.phase[f * Fb + k], &s, &c);
+        float m = p.mag[f * Fb + k];
+        v = make_float2(m * c, m * s);
+      }
+      if (k == 0 || k == M) v.y = 0.f;
+      xs[k] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+      float2 xk = xs[k];
+      float2 xp = xs[M - k];
+      xp.y = -xp.y;
+      float2 e = make_float2(xk.x + xp.x, xk.y + xp.y);
+      float2 w;
+      if (sp) {
+        w = sp[k];
+      } else {
+        float s, c;
+        sincospif(2.0f * (float)k / (float)Nf, &s, &c);  // conj(W_N^k)
+        w = make_float2(c, s);
+      }
+      float2 d = g_cmul(make_float2(xk.x - xp.x, xk.y - xp.y), w);
+      a[k] = make_float2(e.x - d.y, e.y + d.x);
+    }
+    __syncthreads();
+    float2* z = stockham(a, b, M, +1.0f, tw);
+    float2* dst = reinterpret_cast<float2*>(p.frames + f * Nf);
+    for (int n = threadIdx.x; n < M; n += blockDim.x)
+      dst[n] = make_float2((z[n].x * sc) * p.window[2 * n], (z[n].y * sc) * p.window[2 * n + 1]);
+    __syncthreads();
+  }
 }
 
 struct OlaParams {
@@ -269,29 +306,34 @@ static int set_lds(const void* fn, size_t bytes) {
   return 0;
 }
 
+// workgroups of a launch: every frame its own while there are few, a few resident rounds of frame walkers above that
+static unsigned frame_walkers(long long nframes) {
+  const long long cap = 256LL * 16;
+  return (unsigned)(nframes < cap ? nframes : cap);
+}
+
 int launch_rfft_generic(const float* x, long long B, long long L, long long clip_stride, long long T, int n_fft,
                         int hop, int center, const float* window, float2* out, float* phase, hipStream_t stream) {
   if (B * T == 0) return 0;
-  if (B * T >= (1LL << 31)) return -2;       // one workgroup per frame: the grid is 32-bit (AT_EUNSUPPORTED)
-  const int use_tw = n_fft <= 4096;
+  const int use_tw = n_fft <= 8192;      // 16384: the tables do not fit next to the two frame buffers
   GenFwdParams p = {x, window, out, phase, B, L, clip_stride, T, n_fft, hop, center, use_tw};
-  size_t lds = sizeof(float2) * (size_t)(n_fft + (use_tw ? 3 * n_fft / 8 + 1 : 0));  // 2 * M (+ 3 M / 4 + 1 twiddles)
+  // 2 M (+ 3 M / 4 + 1 FFT twiddles + M + 1 split twiddles)
+  size_t lds = sizeof(float2) * (size_t)(n_fft + (use_tw ? 3 * n_fft / 8 + 1 + n_fft / 2 + 1 : 0));
   if (set_lds((const void*)rfft_generic_kernel, lds)) return -5;
   int threads = n_fft / 4 < 64 ? 64 : (n_fft / 4 > 256 ? 256 : n_fft / 4);
-  hipLaunchKernelGGL(rfft_generic_kernel, dim3((unsigned)(B * T)), dim3(threads), lds, stream, p);
+  hipLaunchKernelGGL(rfft_generic_kernel, dim3(frame_walkers(B * T)), dim3(threads), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int launch_irfft_generic(const float2* X, const float* mag, const float* phase, long long nframes, int n_fft,
                          const float* window, float* frames, hipStream_t stream) {
   if (nframes == 0) return 0;
-  if (nframes >= (1LL << 31)) return -2;     // AT_EUNSUPPORTED rather than a wrapped grid
-  const int use_tw = n_fft <= 4096;
-  GenInvParams p = {X, mag, phase, window, frames, n_fft, use_tw};
-  size_t lds = sizeof(float2) * (size_t)(n_fft + 2 + (use_tw ? 3 * n_fft / 8 + 1 : 0));   // a, b (+ twiddles)
+  const int use_tw = n_fft <= 8192;      // 16384: the tables do not fit next to the two frame buffers
+  GenInvParams p = {X, mag, phase, window, frames, nframes, n_fft, use_tw};
+  size_t lds = sizeof(float2) * (size_t)(n_fft + 2 + (use_tw ? 3 * n_fft / 8 + 1 + n_fft / 2 + 1 : 0));   // a, b (+ twiddles)
   if (set_lds((const void*)irfft_generic_kernel, lds)) return -5;
   int threads = n_fft / 4 < 64 ? 64 : (n_fft / 4 > 256 ? 256 : n_fft / 4);
-  hipLaunchKernelGGL(irfft_generic_kernel, dim3((unsigned)nframes), dim3(threads), lds, stream, p);
+  hipLaunchKernelGGL(irfft_generic_kernel, dim3(frame_walkers(nframes)), dim3(threads), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -1,6 +1,6 @@
 // stft_mixed.hip -- STFT frames / inverse frames for the FFT sizes that are NOT a power of two (the reference takes
 // any n_fft: transforms/stft.py:67-75 hands it to torch.stft; 400, 441, 1000, 1200, 1920, 2000 are everyday values
-// at 16 / 44.1 / 48 kHz).  One workgroup per frame, mixed-radix Stockham autosort in LDS: radix 4 / 2 / 3 / 5 / 7
+// at 16 / 44.1 / 48 kHz).  One workgroup per frame at a time, mixed-radix Stockham autosort in LDS: radix 4 / 2 / 3 / 5 / 7
 // butterflies in registers, any other prime factor p by a direct p-point DFT per output (O(p) per point: slow for a
 // large prime, correct for every size).  Even n_fft: the usual half-size complex transform + split; odd n_fft: a
 // full-size complex transform of the real frame.  Correctness path, like stft_generic.hip; the power-of-two sizes
@@ -129,6 +129,16 @@ struct MixFwdParams {
   MixPlan plan;
 };
 
+// exp(sign * 2 pi i k / n_fft), k = 0 .. M: the twiddle of the real split (even sizes), once per workgroup
+__device__ void mx_fill_split(float2* sp, int M, float sign) {
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+    float s, c;
+    sincospif(sign * (float)k / (float)M, &s, &c);
+    sp[k] = make_float2(c, s);
+  }
+}
+
+// A workgroup walks frames blockIdx.x + k gridDim.x with its tables filled once.
 __global__ void rfft_mixed_kernel(MixFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float2 sm[];
   const int Nf = p.n_fft;
@@ -137,44 +147,54 @@ __global__ void rfft_mixed_kernel(MixFwdParams p) {
   float2* a = sm;
   float2* b = sm + M;
   float2* tw = p.use_tw ? sm + 2 * M : nullptr;
+  float2* sp = (p.use_tw && even) ? tw + M : nullptr;
   if (tw) mx_fill_twiddles(tw, M, -1.0f);
-  const long long f = blockIdx.x;
-  const long long bidx = f / p.T, t = f - bidx * p.T;
-  const float* clip = p.x + bidx * p.clip_stride;
-  const long long start = t * (long long)p.hop - (p.center ? Nf / 2 : 0);
-  auto sample = [&](int n) -> float {
-    const long long i = start + n;
-    const float v = p.center ? clip[mx_reflect(i, p.L)] : (i < p.L ? clip[i] : 0.f);
-    return v * p.window[n];
-  };
-  if (even) {
-    for (int n = threadIdx.x; n < M; n += blockDim.x) a[n] = make_float2(sample(2 * n), sample(2 * n + 1));
-  } else {
-    for (int n = threadIdx.x; n < M; n += blockDim.x) a[n] = make_float2(sample(n), 0.f);
-  }
-  __syncthreads();
-  const float2* Z = mx_fft(a, b, M, -1.0f, tw, p.plan);
+  if (sp) mx_fill_split(sp, M, -1.0f);
   const int Fb = Nf / 2 + 1;
-  float2* row = p.out + f * Fb;
-  float* prow = p.phase ? p.phase + f * Fb : nullptr;
-  for (int k = threadIdx.x; k < Fb; k += blockDim.x) {
-    float2 X;
+  for (long long f = blockIdx.x; f < p.B * p.T; f += gridDim.x) {
+    const long long bidx = f / p.T, t = f - bidx * p.T;
+    const float* clip = p.x + bidx * p.clip_stride;
+    const long long start = t * (long long)p.hop - (p.center ? Nf / 2 : 0);
+    auto sample = [&](int n) -> float {
+      const long long i = start + n;
+      const float v = p.center ? clip[mx_reflect(i, p.L)] : (i < p.L ? clip[i] : 0.f);
+      return v * p.window[n];
+    };
     if (even) {
-      const float2 zk = Z[k == M ? 0 : k];
-      float2 zp = Z[k == 0 ? 0 : M - k];
-      zp.y = -zp.y;
-      const float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y + zp.y));
-      const float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y - zp.y));
-      float s, c;
-      sincospif(-2.0f * (float)k / (float)Nf, &s, &c);
-      const float2 wd = mx_cmul(make_float2(c, s), d);
-      X = make_float2(e.x + wd.y, e.y - wd.x);
-      if (k == M) X = make_float2(Z[0].x - Z[0].y, 0.f);
+      for (int n = threadIdx.x; n < M; n += blockDim.x) a[n] = make_float2(sample(2 * n), sample(2 * n + 1));
     } else {
-      X = Z[k];
+      for (int n = threadIdx.x; n < M; n += blockDim.x) a[n] = make_float2(sample(n), 0.f);
     }
-    row[k] = X;
-    if (prow) prow[k] = fast_atan2f(X.y, X.x);
+    __syncthreads();
+    const float2* Z = mx_fft(a, b, M, -1.0f, tw, p.plan);
+    float2* row = p.out + f * Fb;
+    float* prow = p.phase ? p.phase + f * Fb : nullptr;
+    for (int k = threadIdx.x; k < Fb; k += blockDim.x) {
+      float2 X;
+      if (even) {
+        const float2 zk = Z[k == M ? 0 : k];
+        float2 zp = Z[k == 0 ? 0 : M - k];
+        zp.y = -zp.y;
+        const float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y + zp.y));
+        const float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y - zp.y));
+        float2 w;
+        if (sp) {
+          w = sp[k];
+        } else {
+          float s, c;
+          sincospif(-2.0f * (float)k / (float)Nf, &s, &c);
+          w = make_float2(c, s);
+        }
+        const float2 wd = mx_cmul(w, d);
+        X = make_float2(e.x + wd.y, e.y - wd.x);
+        if (k == M) X = make_float2(Z[0].x - Z[0].y, 0.f);
+      } else {
+        X = Z[k];
+      }
+      row[k] = X;
+      if (prow) prow[k] = fast_atan2f(X.y, X.x);
+    }
+    __syncthreads();       // the next frame overwrites the buffers these reads came from
   }
 }
 
@@ -184,6 +204,7 @@ struct MixInvParams {
   const float* phase;
   const float* window;
   float* frames;  // (frames, n_fft)
+  long long nframes;
   int n_fft, use_tw;
   MixPlan plan;
 };
@@ -196,53 +217,63 @@ __global__ void irfft_mixed_kernel(MixInvParams p) {
   float2* a = sm;
   float2* b = sm + M;       // M + 2 entries: until the FFT starts it stages the one-sided spectrum (even sizes)
   float2* tw = p.use_tw ? b + M + 2 : nullptr;
+  float2* sp = (p.use_tw && even) ? tw + M : nullptr;
   if (tw) mx_fill_twiddles(tw, M, +1.0f);
-  const long long f = blockIdx.x;
-  auto bin = [&](int k) -> float2 {
-    float2 v;
-    if (p.X) {
-      v = p.X[f * Fb + k];
-    } else {
-      float s, c;
-      sincosf(p.phase[f * Fb + k], &s, &c);
-      const float m = p.mag[f * Fb + k];
-      v = make_float2(m * c, m * s);
-    }
-    if (k == 0 || (even && k == M)) v.y = 0.f;     // a real signal: DC (and Nyquist) carry no imaginary part
-    return v;
-  };
-  if (even) {
-    float2* xs = b;
-    for (int k = threadIdx.x; k <= M; k += blockDim.x) xs[k] = bin(k);
-    __syncthreads();
-    for (int k = threadIdx.x; k < M; k += blockDim.x) {
-      const float2 xk = xs[k];
-      float2 xp = xs[M - k];
-      xp.y = -xp.y;
-      const float2 e = mx_add(xk, xp);
-      float s, c;
-      sincospif(2.0f * (float)k / (float)Nf, &s, &c);  // conj(W_N^k)
-      const float2 d = mx_cmul(make_float2(xk.x - xp.x, xk.y - xp.y), make_float2(c, s));
-      a[k] = make_float2(e.x - d.y, e.y + d.x);
-    }
-  } else {
-    for (int k = threadIdx.x; k < Fb; k += blockDim.x) {     // Hermitian extension of the one-sided spectrum
-      const float2 v = bin(k);
-      a[k] = v;
-      if (k) a[Nf - k] = make_float2(v.x, -v.y);
-    }
-  }
-  __syncthreads();
-  const float2* z = mx_fft(a, b, M, +1.0f, tw, p.plan);
+  if (sp) mx_fill_split(sp, M, +1.0f);       // conj(W_N^k)
   const float sc = 1.0f / (float)Nf;
-  float* dst = p.frames + f * Nf;
-  if (even) {
-    for (int n = threadIdx.x; n < M; n += blockDim.x) {
-      dst[2 * n] = (z[n].x * sc) * p.window[2 * n];
-      dst[2 * n + 1] = (z[n].y * sc) * p.window[2 * n + 1];
+  for (long long f = blockIdx.x; f < p.nframes; f += gridDim.x) {
+    auto bin = [&](int k) -> float2 {
+      float2 v;
+      if (p.X) {
+        v = p.X[f * Fb + k];
+      } else {
+        float s, c;
+        sincosf(p.phase[f * Fb + k], &s, &c);
+        const float m = p.mag[f * Fb + k];
+        v = make_float2(m * c, m * s);
+      }
+      if (k == 0 || (even && k == M)) v.y = 0.f;     // a real signal: DC (and Nyquist) carry no imaginary part
+      return v;
+    };
+    if (even) {
+      float2* xs = b;
+      for (int k = threadIdx.x; k <= M; k += blockDim.x) xs[k] = bin(k);
+      __syncthreads();
+      for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        const float2 xk = xs[k];
+        float2 xp = xs[M - k];
+        xp.y = -xp.y;
+        const float2 e = mx_add(xk, xp);
+        float2 w;
+        if (sp) {
+          w = sp[k];
+        } else {
+          float s, c;
+          sincospif(2.0f * (float)k / (float)Nf, &s, &c);  // conj(W_N^k)
+          w = make_float2(c, s);
+        }
+        const float2 d = mx_cmul(make_float2(xk.x - xp.x, xk.y - xp.y), w);
+        a[k] = make_float2(e.x - d.y, e.y + d.x);
+      }
+    } else {
+      for (int k = threadIdx.x; k < Fb; k += blockDim.x) {     // Hermitian extension of the one-sided spectrum
+        const float2 v = bin(k);
+        a[k] = v;
+        if (k) a[Nf - k] = make_float2(v.x, -v.y);
+      }
     }
-  } else {
-    for (int n = threadIdx.x; n < M; n += blockDim.x) dst[n] = (z[n].x * sc) * p.window[n];
+    __syncthreads();
+    const float2* z = mx_fft(a, b, M, +1.0f, tw, p.plan);
+    float* dst = p.frames + f * Nf;
+    if (even) {
+      for (int n = threadIdx.x; n < M; n += blockDim.x) {
+        dst[2 * n] = (z[n].x * sc) * p.window[2 * n];
+        dst[2 * n + 1] = (z[n].y * sc) * p.window[2 * n + 1];
+      }
+    } else {
+      for (int n = threadIdx.x; n < M; n += blockDim.x) dst[n] = (z[n].x * sc) * p.window[n];
+    }
+    __syncthreads();
   }
 }
 
@@ -275,29 +306,32 @@ static int mix_threads(int M) {
   return t < 64 ? 64 : (t > 256 ? 256 : t);
 }
 
+static unsigned mix_walkers(long long nframes) {
+  const long long cap = 256LL * 16;
+  return (unsigned)(nframes < cap ? nframes : cap);
+}
+
 int launch_rfft_mixed(const float* x, long long B, long long L, long long clip_stride, long long T, int n_fft, int hop,
                       int center, const float* window, float2* out, float* phase, hipStream_t stream) {
   if (B * T == 0) return 0;
-  if (B * T >= (1LL << 31)) return -2;
   const int M = (n_fft & 1) ? n_fft : n_fft / 2;
   MixFwdParams p = {x, window, out, phase, B, L, clip_stride, T, n_fft, hop, center, M <= 4096, {}};
   if (!mix_plan(M, &p.plan)) return -2;
-  const size_t lds = sizeof(float2) * (size_t)(2 * M + (p.use_tw ? M : 0));
+  const size_t lds = sizeof(float2) * (size_t)(2 * M + (p.use_tw ? 2 * M + 1 : 0));     // a, b (+ FFT and split twiddles)
   if (mix_set_lds((const void*)rfft_mixed_kernel, lds)) return -5;
-  hipLaunchKernelGGL(rfft_mixed_kernel, dim3((unsigned)(B * T)), dim3(mix_threads(M)), lds, stream, p);
+  hipLaunchKernelGGL(rfft_mixed_kernel, dim3(mix_walkers(B * T)), dim3(mix_threads(M)), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int launch_irfft_mixed(const float2* X, const float* mag, const float* phase, long long nframes, int n_fft,
                        const float* window, float* frames, hipStream_t stream) {
   if (nframes == 0) return 0;
-  if (nframes >= (1LL << 31)) return -2;
   const int M = (n_fft & 1) ? n_fft : n_fft / 2;
-  MixInvParams p = {X, mag, phase, window, frames, n_fft, M <= 4096, {}};
+  MixInvParams p = {X, mag, phase, window, frames, nframes, n_fft, M <= 4096, {}};
   if (!mix_plan(M, &p.plan)) return -2;
-  const size_t lds = sizeof(float2) * (size_t)(2 * M + 2 + (p.use_tw ? M : 0));
+  const size_t lds = sizeof(float2) * (size_t)(2 * M + 2 + (p.use_tw ? 2 * M + 1 : 0));
   if (mix_set_lds((const void*)irfft_mixed_kernel, lds)) return -5;
-  hipLaunchKernelGGL(irfft_mixed_kernel, dim3((unsigned)nframes), dim3(mix_threads(M)), lds, stream, p);
+  hipLaunchKernelGGL(irfft_mixed_kernel, dim3(mix_walkers(nframes)), dim3(mix_threads(M)), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
