@@ -173,6 +173,30 @@ def test_mfcc_melspectrogram(dev):
     assert rel_max(cpu(c), cr.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("n,h,n_mels,L", [(2048, 512, 128, 30000), (512, 128, 64, 9001), (4096, 1024, 128, 50000),
+                                          (256, 64, 40, 5000), (2048, 512, 80, 2048 * 3 + 17), (400, 160, 40, 16000),
+                                          (1024, 100, 128, 7000)])
+def test_melspectrogram_at_other_sizes(dev, n, h, n_mels, L):
+    """MFCC (= MelSpectrogram, mel.py:31-73) away from the fused n_fft 1024 / hop 256 kernel: STFT + the banded walk
+    with its channel-major register window (one- and two-pass banks, runs of rows that start and end inside a clip,
+    frame counts that are not a multiple of eight), and the DCT behind n_mfcc."""
+    torch.manual_seed(n + h)
+    x = torch.randn(5, 3, L) * 0.1
+    f = A.MFCC(n_fft=n, hop_length=h, n_mels=n_mels).to(dev)
+    y = f(x.to(dev))
+    yr = O.melspectrogram(x, 44100, n, h, n_mels, 2.0)
+    assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL
+    fn = A.MFCC(n_fft=n, hop_length=h, n_mels=n_mels, norm_mode="gaussian").to(dev)
+    fn.scale_data(x.to(dev))
+    off, sc = O.normalize_stats(x, "gaussian")
+    assert rel_max(cpu(fn(x.to(dev))), ((yr - off) / sc).numpy()) < TOL
+    n_mfcc = min(40, n_mels)
+    c = A.MFCC(n_fft=n, hop_length=h, n_mels=n_mels, n_mfcc=n_mfcc).to(dev)(x.to(dev))
+    db = 10.0 * torch.log10(torch.clamp(yr, min=1e-10)).transpose(-1, -2)
+    cr = O.mfcc_dct(db, n_mfcc).transpose(-1, -2)
+    assert c.shape == cr.shape and rel_max(cpu(c), cr.numpy()) < 2e-5
+
+
 def test_zero_block_skipping_keeps_dense_semantics(dev):
     """Banded banks skip all-zero bank blocks; results must equal the dense contraction, including
     inf/NaN propagation (0 * NaN = NaN in a dense matmul), and a dense bank must be unaffected."""
