@@ -526,20 +526,22 @@ def istft_griffinlim(mag, rebuilt, tprev, momentum_over_1p, inv_window, n_fft, h
 
 
 def stft_mel_forward(x, window, band, contrast=None, offset=None, scale=None, eps=1.1920929e-07, power=1,
-                     want_spectrum=True, want_phase=False, channel_major=False, hop=256):
+                     want_spectrum=True, want_phase=False, channel_major=False, hop=256, n_fft=1024):
     """Fused n_fft=1024 forward (hop 256; 128 / 512 without channel_major): x (B, L) -> (X (B,T,513) complex64 or
-    None, phase or None, features).  `band` is a utils.banded.BandedBank (eligible).  features: (B, T, N), or
-    (B, N, T) when channel_major."""
+    None, phase or None, features).  `band` is a utils.banded.BandedBank (fusable).  features: (B, T, N), or
+    (B, N, T) when channel_major.  n_fft=2048 (any hop): features only (want_spectrum=False)."""
     require_device(x, window)
     x = _f32c(x)
     B, L = x.shape
     T = 1 + L // hop
+    F = n_fft // 2 + 1
+    assert n_fft == 1024 or (n_fft == 2048 and not want_spectrum)
     lane_filter, lane_start, weights = band.on(x.device)
     N = band.N
-    X = torch.empty((B, T, 513), dtype=torch.complex64, device=x.device) if want_spectrum else None
-    phase = torch.empty((B, T, 513), dtype=torch.float32, device=x.device) if (want_phase and want_spectrum) else None
+    X = torch.empty((B, T, F), dtype=torch.complex64, device=x.device) if want_spectrum else None
+    phase = torch.empty((B, T, F), dtype=torch.float32, device=x.device) if (want_phase and want_spectrum) else None
     feat = torch.empty((B, N, T) if channel_major else (B, T, N), dtype=torch.float32, device=x.device)
-    check(lib().at_stft_mel_forward(ptr(x), B, L, L, T, 1024, hop, ptr(window), ptr(lane_filter), ptr(lane_start),
+    check(lib().at_stft_mel_forward(ptr(x), B, L, L, T, n_fft, hop, ptr(window), ptr(lane_filter), ptr(lane_start),
                                     ptr(weights), N, band.n_passes, band.pass_len.ctypes.data,
                                     contrast_code(contrast), int(power == 2),
                                     ptr(offset), ptr(scale), eps, ptr(X), ptr(phase), ptr(feat), int(channel_major),

@@ -130,7 +130,7 @@ class BandedBank:
         self.lmax = int((n_quads * 4).max()) if N else 0
         self.n_passes = (N + 63) // 64
         self.executed_macs = int(np.where(has, last - first + 1, 0).sum())   # useful multiply-adds per frame
-        self.eligible = self.fusable = False
+        self.eligible = self.fusable = self.fusable2048 = False
         if not (0 < N and self.n_passes <= MAX_PASSES and self.lmax <= MAX_BAND and K <= MAX_ROW):
             return
         # passes: filters sorted by band length, 64 per pass, so that every pass walks bands of similar length
@@ -169,6 +169,13 @@ class BandedBank:
         self.fusable = (self.n_passes <= FUSED_MAX_PASSES and self.lmax <= FUSED_MAX_BAND
                         and weights.size <= FUSED_TABLE_FLOATS
                         and int(lane_start.max()) + int(pass_len.max()) <= FUSED_ROW_FLOATS)
+        # the features-only n_fft = 2048 kernel (stft2048.hip): same walk limits, its own LDS row (sized per launch)
+        # and the whole workgroup within 80 KB of LDS (launch_stft2048_mel)
+        row2k = -(-(1025 + int(pass_len.max())) // 64) * 64
+        self.fusable2048 = (K == 1025 and self.n_passes <= FUSED_MAX_PASSES and self.lmax <= FUSED_MAX_BAND
+                            and weights.size <= FUSED_TABLE_FLOATS
+                            and 8 * (4 * 568 + 22 * 64 + 1024) + 4 * (4 * row2k + weights.size) + 8 * 64 * self.n_passes
+                            <= 80 * 1024)
         self.pass_len = pass_len                              # host array handed to the C ABI
         self.walked_macs = 64 * int(pass_len.sum())           # multiply-adds issued per frame (incl. zeros)
         self._host = (lane_filter, lane_start, weights)
