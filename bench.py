@@ -623,6 +623,15 @@ def main():
         res["if_invert_central"] = entry(timed_ms(lambda: _ops.phase_integrate(inst, "central"), 5, 1), 8)
         mg_ = Xs.abs()
         res["polar_to_complex"] = entry(timed_ms(lambda: _ops.polar_to_complex(mg_, inst), 5, 1), 16)
+        del inst, mg_
+        # the stacked representations (one pass over the spectrum each way; 8 B in, 8 B out per bin)
+        for name, tr in (("polar", A.Polar()), ("polar_if", A.PolarIF()), ("cartesian", A.Cartesian())):
+            tr = tr.to(dev)
+            tr.scale_data(Xs)
+            yy = tr(Xs)
+            res[name + "_forward"] = entry(timed_ms(lambda: tr(Xs), 3, 1), 16)
+            res[name + "_invert"] = entry(timed_ms(lambda: tr.invert(yy), 3, 1), 16)
+            del yy
         return res
 
     def extra_hbm_probe():
@@ -666,6 +675,9 @@ def main():
                                    "forward_frac_of_8TBps": round(frames * bytes_per_frame / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "inverse_frac_of_8TBps": round(frames * bytes_per_frame / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del Xh
+        # MelSpectrogram at torchaudio's / librosa's usual 2048 / 512 / 128 mels: one kernel, the spectrum is never written
+        ms_ = A.MFCC(sr=SR, n_fft=2048, hop_length=512, n_mels=128).to(dev)
+        res["melspectrogram_2048_512_128"] = {"ms": round(timed_ms(lambda: ms_(x), 3, 1), 4)}
         st = A.STFT(sr=SR, n_fft=400, hop_length=160).to(dev)
         Xh = st(x)
         res["n_fft_400_hop_160"] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(timed_ms(lambda: st(x), 3, 1), 4),
