@@ -34,6 +34,8 @@ int launch_stft2048_fwd(const float*, long long, long long, long long, long long
                         const float2*, float2*, float*, hipStream_t);
 int launch_irfft2048_frames(const float2*, const float*, const float*, long long, const float*, const float2*,
                             const float2*, float*, hipStream_t);
+int launch_stft512_mel(const float*, long long, long long, long long, long long, int, const float*, const float2*,
+                       const float2*, const BandBank*, int, int, const float*, const float*, float, float*, int, hipStream_t);
 int launch_stft2048_mel(const float*, long long, long long, long long, long long, int, const float*, const float2*,
                         const float2*, const BandBank*, int, int, const float*, const float*, float, float*, int, hipStream_t);
 int launch_istft2048_ola(const float2*, const float*, const float*, long long, long long, int, const float*,
@@ -239,7 +241,8 @@ int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_strid
                         float* out_complex_or_null, float* phase_or_null, float* feat, int feat_channel_major,
                         void* stream) {
   if (B < 0 || T < 0 || L < 0) return AT_EINVAL;
-  const bool feat_only_2048 = n_fft == 2048 && hop >= 1 && !out_complex_or_null && !phase_or_null;   // stft2048.hip
+  // features only at n_fft 2048 / 512 (stft2048.hip, stft512.hip)
+  const bool feat_only_2048 = (n_fft == 2048 || n_fft == 512) && hop >= 1 && !out_complex_or_null && !phase_or_null;
   if (!feat_only_2048) {
     if (n_fft != 1024 || (hop != 256 && hop != 128 && hop != 512) || (clip_stride & 1)) return AT_EUNSUPPORTED;
     if (hop != 256 && feat_channel_major) return AT_EUNSUPPORTED;
@@ -248,7 +251,7 @@ int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_strid
   if (!x || !window || !feat || !lane_filter || !lane_start || !band_weights || !pass_len_host) return AT_EINVAL;
   if (n_filters <= 0 || n_passes <= 0 || n_passes > 16 || n_filters > 64 * n_passes) return AT_EINVAL;
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
-  if (L <= n_fft / 2 || (((uintptr_t)window) & (feat_only_2048 ? 15 : 7)) || (((uintptr_t)band_weights) & 15)) return AT_EINVAL;
+  if (L <= n_fft / 2 || (((uintptr_t)window) & (n_fft == 2048 ? 15 : 7)) || (((uintptr_t)band_weights) & 15)) return AT_EINVAL;
   const float2* tw = twiddles_for_current_device();
   if (!tw) return AT_ENOTINIT;
   BandBank bank = {lane_filter, lane_start, band_weights, n_filters, n_passes, {0}};
@@ -262,6 +265,9 @@ int at_stft_mel_forward(const float* x, int64_t B, int64_t L, int64_t clip_strid
   if (feat_only_2048) {
     const float2* tw2k = tw2048_for_current_device();
     if (!tw2k) return AT_ENOTINIT;
+    if (n_fft == 512)
+      return launch_stft512_mel(x, B, L, clip_stride, T, hop, window, tw, tw2k + 1024, &bank, contrast, power2, offset, scale, eps,
+                                feat, feat_channel_major, (hipStream_t)stream);
     return launch_stft2048_mel(x, B, L, clip_stride, T, hop, window, tw, tw2k, &bank, contrast, power2, offset, scale, eps, feat,
                                feat_channel_major, (hipStream_t)stream);
   }

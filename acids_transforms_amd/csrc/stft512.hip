@@ -19,6 +19,8 @@
 #include "../../include/acids_hip.h"
 #include "fastmath.h"
 #include "fft512.h"
+#include "band_bank.h"
+#include "mel_gemm.h"   // C_* contrast codes
 
 namespace at_hip {
 
@@ -420,6 +422,255 @@ static long long pairs_per_block_5(long long npairs) {
   long long ppb = (npairs + max_blocks - 1) / max_blocks;
   ppb = ((ppb + W5 - 1) / W5) * W5;
   return ppb < W5 ? W5 : ppb;
+}
+
+// ---------------------------------------------------------------------------
+// Features-only forward for n_fft = 512, any hop: audio -> normalise(contrast(|X|^p @ bank)) for a banded bank
+// (MelSpectrogram / MFCC at the usual speech setting; mel.py:43-44, 68-73 behind stft.py:98-104).  The forward kernel
+// with both spectra of a frame pair kept in registers: |X|^p of frames A and B go into two LDS rows of the wave and the
+// band walk reads every weight quad once for both rows.  Output row-major, or channel-major through the eight-frame
+// register window with sector-aligned flushes (mel_banded.hip).  A wave takes a run of consecutive frame pairs.
+// ---------------------------------------------------------------------------
+struct P5Mel {
+  const float* x;
+  const float* window;
+  const float2* tw;
+  const float2* tw512;
+  float* feat;           // (B*T, N) or (B, N, T)
+  const float* offset;
+  const float* scale;
+  long long L, clip_stride, T, total_frames, pairs_per_wave;
+  BandBank bank;
+  int hop, contrast, power2, channel_major, row_floats, table_floats;
+  float eps;
+};
+
+__device__ __forceinline__ float contrast5(float v, int mode, float eps) {
+  switch (mode) {
+    case C_LOG1P: return logf(1.0f + v);
+    case C_LOG: return logf(fmaxf(v, eps));
+    case C_LOG10: return log10f(fmaxf(v, eps));
+    default: return v;
+  }
+}
+
+template <int CMW>    // 1 / 2: channel-major output of a bank with that many passes (register window); 0: anything else
+__global__ __launch_bounds__(64 * W5) void stft512_mel_kernel(P5Mel p) {
+  __shared__ float2 lds_all[W5 * kFftLdsFloat2PerWave];
+  extern __shared__ __attribute__((aligned(16))) float dyn5[];      // rows (two per wave), weights, lane tables
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float* rowa = dyn5 + (2 * wave) * p.row_floats;
+  float* rowb = rowa + p.row_floats;
+  float* wlds = dyn5 + 2 * W5 * p.row_floats;
+  int* lane_tab = reinterpret_cast<int*>(wlds + p.table_floats);
+  for (int i = threadIdx.x; i < p.table_floats; i += 64 * W5) wlds[i] = p.bank.weights[i];
+  for (int i = threadIdx.x; i < 64 * p.bank.n_passes; i += 64 * W5) {
+    lane_tab[i] = p.bank.lane_start[i];
+    lane_tab[64 * p.bank.n_passes + i] = p.bank.lane_filter[i];
+  }
+  for (int k = 256 + lane; k < p.row_floats; k += 64) rowa[k] = rowb[k] = 0.0f;      // bin 256 is rewritten per frame
+  __syncthreads();
+  Twiddles tw;
+  load_twiddles<false>(tw, p.tw, lane);
+  v2f w5[4];
+  float2 win[8];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const float2 a = p.tw512[lane + 64 * m];
+    w5[m] = (v2f){a.x, a.y};
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) win[j] = reinterpret_cast<const float2*>(p.window)[(lane >> 1) + 32 * j];
+  const long long n_pairs = (p.total_frames + 1) / 2;
+  const long long pr_begin = ((long long)blockIdx.x * W5 + wave) * p.pairs_per_wave;
+  long long pr_end = pr_begin + p.pairs_per_wave;
+  if (pr_end > n_pairs) pr_end = n_pairs;
+  if (pr_begin >= pr_end) return;
+  const v2f hh = {0.5f, 0.5f};
+  float off = 0.f, sc = 1.f;
+  if (p.offset) {
+    off = *p.offset;
+    sc = *p.scale;
+  }
+  P5 lp = {};
+  lp.x = p.x; lp.L = p.L; lp.clip_stride = p.clip_stride; lp.T = p.T; lp.total_frames = p.total_frames; lp.hop = p.hop;
+  lp.center = 1;
+  long long f_last = 2 * pr_end - 1;                     // last frame of this wave's run
+  if (f_last > p.total_frames - 1) f_last = p.total_frames - 1;
+
+  float cm[CMW > 0 ? CMW : 1][8];
+  long long e_next[CMW > 0 ? CMW : 1];
+  int held[CMW > 0 ? CMW : 1];
+#pragma unroll
+  for (int q = 0; q < (CMW > 0 ? CMW : 1); ++q) {
+    held[q] = 0;
+    e_next[q] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cm[q][k] = 0.f;
+  }
+  bool e_valid = false;
+  long long cb = (2 * pr_begin) / p.T, ct = 2 * pr_begin - cb * p.T;
+  int fq[CMW > 0 ? CMW : 1];
+  if (CMW > 0) {
+#pragma unroll
+    for (int q = 0; q < (CMW > 0 ? CMW : 1); ++q) fq[q] = lane_tab[(CMW + q) * 64 + lane];
+  }
+
+  // one frame's features out: row-major / scalar channel-major, or through the window
+  auto emit = [&](long long f, const float (&acc_q)[16], int n_acc) {
+    const long long b = cb, t = ct;
+    if (++ct == p.T) {
+      ct = 0;
+      ++cb;
+    }
+    if constexpr (CMW > 0) {
+      const bool last_of_run = (t == p.T - 1) || (f == f_last);
+#pragma unroll
+      for (int q = 0; q < CMW; ++q) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cm[q][k] = cm[q][k + 1];
+        cm[q][7] = acc_q[q];
+        ++held[q];
+        if (fq[q] >= 0) {
+          if (!e_valid) e_next[q] = (b * p.bank.n_filters + fq[q]) * p.T + t + 1;
+          const long long e = e_next[q];
+          e_next[q] = e + ((t == p.T - 1) ? (long long)(p.bank.n_filters - 1) * p.T + 1 : 1);
+          if ((e & 7) == 0 || last_of_run) {
+            float* dst = p.feat + e - 8;
+            if (held[q] >= 8) {
+              if ((e & 3) == 0) {
+                reinterpret_cast<float4*>(dst)[0] = make_float4(cm[q][0], cm[q][1], cm[q][2], cm[q][3]);
+                reinterpret_cast<float4*>(dst)[1] = make_float4(cm[q][4], cm[q][5], cm[q][6], cm[q][7]);
+              } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dst[k] = cm[q][k];
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                if (k >= 8 - held[q]) dst[k] = cm[q][k];
+            }
+            held[q] = 0;
+          }
+        } else if (last_of_run) {
+          held[q] = 0;
+        }
+      }
+      e_valid = true;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {                       // static indices into the accumulator registers
+        if (q < n_acc) {
+          const int filt = lane_tab[(p.bank.n_passes + q) * 64 + lane];
+          if (filt >= 0) {
+            if (p.channel_major) p.feat[(b * p.bank.n_filters + filt) * p.T + t] = acc_q[q];
+            else p.feat[f * p.bank.n_filters + filt] = acc_q[q];
+          }
+        }
+      }
+    }
+  };
+
+  float2 nxt[8];
+  load_half_frame5(lp, 2 * pr_begin + (lane & 1), lane, nxt);
+  for (long long pr = pr_begin; pr < pr_end; ++pr) {
+    v2f y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = (v2f){nxt[j].x * win[j].x, nxt[j].y * win[j].y};
+    if (pr + 1 < pr_end) load_half_frame5(lp, 2 * (pr + 1) + (lane & 1), lane, nxt);
+    fft512<false>(y, tw, lds, lane);
+    v2f ha[4], hb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const v2f s = (y[m] + y[m + 4]) * hh;
+      const v2f d = (y[m] - y[m + 4]) * hh;
+      ha[m] = s * hh;
+      hb[m] = cmul_conj_v(d, w5[m]) * hh;
+    }
+    v2f pa[4], pb[4];
+    mirror256(ha, pa, lane);
+    mirror256(hb, pb, lane);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const v2f xa = add_mi(add_conj(ha[m], pa[m]), cmul_v(sub_conj(ha[m], pa[m]), w5[m]));
+      const v2f xb = add_mi(add_conj(hb[m], pb[m]), cmul_v(sub_conj(hb[m], pb[m]), w5[m]));
+      const float sa = fmaf(xa.x, xa.x, xa.y * xa.y), sb = fmaf(xb.x, xb.x, xb.y * xb.y);
+      rowa[lane + 64 * m] = p.power2 ? sa : __builtin_amdgcn_sqrtf(sa);
+      rowb[lane + 64 * m] = p.power2 ? sb : __builtin_amdgcn_sqrtf(sb);
+    }
+    if (lane == 0) {
+      const float na = 2.0f * (ha[0].x - ha[0].y), nb = 2.0f * (hb[0].x - hb[0].y);
+      rowa[256] = p.power2 ? na * na : fabsf(na);
+      rowb[256] = p.power2 ? nb * nb : fabsf(nb);
+    }
+    wave_lds_sync();
+    // one walk for both frames: every weight quad is read once
+    const float4* w = reinterpret_cast<const float4*>(wlds) + lane;
+    constexpr int NQ = CMW > 0 ? CMW : 16;
+    float fa_q[16], fb_q[16];
+    const int n_acc = CMW > 0 ? CMW : p.bank.n_passes;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q < n_acc) {
+        const int st = lane_tab[q * 64 + lane];
+        const float4* a4 = reinterpret_cast<const float4*>(rowa + st);
+        const float4* b4 = reinterpret_cast<const float4*>(rowb + st);
+        v2f aa = {0.f, 0.f}, ab = {0.f, 0.f};
+        const int quads = p.bank.pass_len[q] >> 2;
+        for (int j = 0; j < quads; ++j) {
+          const float4 wv = w[j * 64], av = a4[j], bv = b4[j];
+          aa = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, aa);
+          aa = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, aa);
+          ab = __builtin_elementwise_fma((v2f){bv.x, bv.y}, (v2f){wv.x, wv.y}, ab);
+          ab = __builtin_elementwise_fma((v2f){bv.z, bv.w}, (v2f){wv.z, wv.w}, ab);
+        }
+        w += quads * 64;
+        float va = contrast5(aa.x + aa.y, p.contrast, p.eps), vb = contrast5(ab.x + ab.y, p.contrast, p.eps);
+        if (p.offset) {
+          va = (va - off) / sc;
+          vb = (vb - off) / sc;
+        }
+        fa_q[q] = va;
+        fb_q[q] = vb;
+      }
+    }
+    emit(2 * pr, fa_q, n_acc);
+    if (2 * pr + 1 < p.total_frames) emit(2 * pr + 1, fb_q, n_acc);
+    wave_lds_sync();
+  }
+}
+
+int launch_stft512_mel(const float* x, long long B, long long L, long long clip_stride, long long T, int hop,
+                       const float* window, const float2* tw, const float2* tw512, const BandBank* bank, int contrast,
+                       int power2, const float* offset, const float* scale, float eps, float* feat, int channel_major,
+                       hipStream_t stream) {
+  const long long nframes = B * T;
+  if (nframes == 0) return 0;
+  P5Mel p = {};
+  p.x = x; p.window = window; p.tw = tw; p.tw512 = tw512; p.feat = feat; p.offset = offset; p.scale = scale;
+  p.L = L; p.clip_stride = clip_stride; p.T = T; p.total_frames = nframes; p.bank = *bank; p.hop = hop;
+  p.contrast = contrast; p.power2 = power2; p.channel_major = channel_major; p.eps = eps;
+  int max_walk = 0, table_floats = 0;
+  for (int q = 0; q < bank->n_passes; ++q) {
+    max_walk = bank->pass_len[q] > max_walk ? bank->pass_len[q] : max_walk;
+    table_floats += 64 * bank->pass_len[q];
+  }
+  p.table_floats = table_floats;
+  p.row_floats = (F5 + max_walk + 63) / 64 * 64;
+  const size_t lds = sizeof(float) * ((size_t)2 * W5 * p.row_floats + table_floats) + sizeof(int) * (size_t)2 * 64 * bank->n_passes;
+  if (lds > 48 * 1024) return -2;
+  const long long npairs = (nframes + 1) / 2;
+  long long ppw = (npairs + 256LL * 8 * W5 - 1) / (256LL * 8 * W5);
+  if (ppw < 4) ppw = 4;
+  p.pairs_per_wave = ppw;
+  const long long waves = (npairs + ppw - 1) / ppw;
+  const unsigned grid = (unsigned)((waves + W5 - 1) / W5);
+  void (*kernel)(P5Mel) = stft512_mel_kernel<0>;
+  if (channel_major && bank->n_passes == 1) kernel = stft512_mel_kernel<1>;
+  else if (channel_major && bank->n_passes == 2) kernel = stft512_mel_kernel<2>;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * W5), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int launch_stft512_fwd(const float* x, long long B, long long L, long long clip_stride, long long T, int hop, int center,

@@ -529,13 +529,13 @@ def stft_mel_forward(x, window, band, contrast=None, offset=None, scale=None, ep
                      want_spectrum=True, want_phase=False, channel_major=False, hop=256, n_fft=1024):
     """Fused n_fft=1024 forward (hop 256; 128 / 512 without channel_major): x (B, L) -> (X (B,T,513) complex64 or
     None, phase or None, features).  `band` is a utils.banded.BandedBank (fusable).  features: (B, T, N), or
-    (B, N, T) when channel_major.  n_fft=2048 (any hop): features only (want_spectrum=False)."""
+    (B, N, T) when channel_major.  n_fft=2048 / 512 (any hop): features only (want_spectrum=False)."""
     require_device(x, window)
     x = _f32c(x)
     B, L = x.shape
     T = 1 + L // hop
     F = n_fft // 2 + 1
-    assert n_fft == 1024 or (n_fft == 2048 and not want_spectrum)
+    assert n_fft == 1024 or (n_fft in (2048, 512) and not want_spectrum)
     lane_filter, lane_start, weights = band.on(x.device)
     N = band.N
     X = torch.empty((B, T, F), dtype=torch.complex64, device=x.device) if want_spectrum else None

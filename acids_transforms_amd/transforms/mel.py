@@ -107,17 +107,18 @@ class MFCC(AudioTransform):
                 off, sc = self.norm._params(x)
             out = ops.mel_forward_real(logmel, self.dct, off, sc, channel_major_T=logmel.shape[-2])
             return out.reshape(batch_shape + out.shape[-2:])
-        if (self.n_fft == 2048 and self._band.fusable2048 and xb.dtype == torch.float32 and xb.shape[-1] > 1024):
-            # the same single kernel for torchaudio's / librosa's usual n_fft = 2048 (any hop): features only
+        if (((self.n_fft == 2048 and self._band.fusable2048) or (self.n_fft == 512 and self._band.fusable512))
+                and xb.dtype == torch.float32 and xb.shape[-1] > self.n_fft // 2):
+            # the same single kernel for torchaudio's / librosa's usual n_fft = 2048 and for 512 (any hop): features only
             if self.n_mfcc is None:
                 off = sc = None
                 if self.norm is not None:
                     off, sc = self.norm._params(x)
                 _, _, mel = ops.stft_mel_forward(xb, self.window, self._band, None, off, sc, power=int(self.power),
-                                                 want_spectrum=False, channel_major=True, hop=self.hop_length, n_fft=2048)
+                                                 want_spectrum=False, channel_major=True, hop=self.hop_length, n_fft=self.n_fft)
                 return mel.reshape(batch_shape + mel.shape[-2:])
             _, _, logmel = ops.stft_mel_forward(xb, self.window, self._band, "log", None, None, eps=1e-10,
-                                                power=int(self.power), want_spectrum=False, hop=self.hop_length, n_fft=2048)
+                                                power=int(self.power), want_spectrum=False, hop=self.hop_length, n_fft=self.n_fft)
             off = sc = None
             if self.norm is not None:
                 off, sc = self.norm._params(x)

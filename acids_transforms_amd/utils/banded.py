@@ -130,7 +130,7 @@ class BandedBank:
         self.lmax = int((n_quads * 4).max()) if N else 0
         self.n_passes = (N + 63) // 64
         self.executed_macs = int(np.where(has, last - first + 1, 0).sum())   # useful multiply-adds per frame
-        self.eligible = self.fusable = self.fusable2048 = False
+        self.eligible = self.fusable = self.fusable2048 = self.fusable512 = False
         if not (0 < N and self.n_passes <= MAX_PASSES and self.lmax <= MAX_BAND and K <= MAX_ROW):
             return
         # passes: filters sorted by band length, 64 per pass, so that every pass walks bands of similar length
@@ -165,6 +165,11 @@ class BandedBank:
         row_floats = -(-max(max(K, 64) + int(pass_len.max()), 64 * kernel_segs) // 64) * 64
         if weights.size * 4 + 2 * 64 * self.n_passes * 4 + 4 * row_floats * 4 > LDS_BUDGET:
             return
+        # the features-only n_fft = 512 kernel (stft512.hip): two LDS rows per wave, dynamic LDS within 48 KB
+        row512 = -(-(257 + int(pass_len.max())) // 64) * 64
+        self.fusable512 = (K == 257 and self.n_passes <= FUSED_MAX_PASSES and self.lmax <= FUSED_MAX_BAND
+                           and weights.size <= FUSED_TABLE_FLOATS
+                           and 4 * (8 * row512 + weights.size) + 8 * 64 * self.n_passes <= 48 * 1024)
         self.eligible = True
         self.fusable = (self.n_passes <= FUSED_MAX_PASSES and self.lmax <= FUSED_MAX_BAND
                         and weights.size <= FUSED_TABLE_FLOATS

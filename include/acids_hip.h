@@ -70,9 +70,9 @@ int at_stft_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, i
  * out_complex_or_null == NULL: features only (MFCC).
  * feat: (B*T, n_filters), or (B, n_filters, T) when feat_channel_major.
  * n_fft = 1024; hop = 256, or 128 / 512 with row-major features (else AT_EUNSUPPORTED).
- * n_fft = 2048 (any hop, window 16-byte aligned, here lane_start + pass_len <= 1025 + 128): features only --
- * out_complex_or_null and phase_or_null must be NULL -- either layout: MelSpectrogram / MFCC at 2048 / 512 in one
- * kernel (stft2048.hip), the spectrum is never written. */
+ * n_fft = 2048 (window 16-byte aligned) or 512, any hop (here lane_start + pass_len <= n_fft/2 + 1 + 128): features
+ * only -- out_complex_or_null and phase_or_null must be NULL -- either layout: MelSpectrogram / MFCC in one kernel
+ * (stft2048.hip, stft512.hip), the spectrum is never written. */
 int at_stft_mel_forward(const float *x, int64_t B, int64_t L, int64_t clip_stride, int64_t T, int n_fft, int hop,
                         const float *window, const int32_t *lane_filter, const int32_t *lane_start,
                         const float *band_weights, int n_filters, int n_passes, const int32_t *pass_len_host,

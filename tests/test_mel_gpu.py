@@ -175,7 +175,8 @@ def test_mfcc_melspectrogram(dev):
 
 @pytest.mark.parametrize("n,h,n_mels,L", [(2048, 512, 128, 30000), (512, 128, 64, 9001), (4096, 1024, 128, 50000),
                                           (256, 64, 40, 5000), (2048, 512, 80, 2048 * 3 + 17), (400, 160, 40, 16000),
-                                          (1024, 100, 128, 7000), (2048, 300, 200, 20001), (2048, 2048, 40, 9000)])
+                                          (1024, 100, 128, 7000), (2048, 300, 200, 20001), (2048, 2048, 40, 9000),
+                                          (512, 160, 80, 16001), (512, 100, 200, 7001), (512, 256, 40, 3000)])
 def test_melspectrogram_at_other_sizes(dev, n, h, n_mels, L):
     """MFCC (= MelSpectrogram, mel.py:31-73) away from the fused n_fft 1024 / hop 256 kernel: STFT + the banded walk
     with its channel-major register window (one- and two-pass banks, runs of rows that start and end inside a clip,
@@ -186,6 +187,7 @@ def test_melspectrogram_at_other_sizes(dev, n, h, n_mels, L):
     # n_fft 2048: one kernel, the spectrum is never written (40 filters over 1025 bins have bands of 168 bins, beyond
     # the fused walk's 128: that bank takes the two-kernel path)
     assert f._band.fusable2048 == (n == 2048 and n_mels != 40)
+    assert f._band.fusable512 == (n == 512)            # likewise (two frames per FFT, one walk for both)
     y = f(x.to(dev))
     yr = O.melspectrogram(x, 44100, n, h, n_mels, 2.0)
     assert y.shape == yr.shape and rel_max(cpu(y), yr.numpy()) < TOL
