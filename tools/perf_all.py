@@ -144,3 +144,33 @@ if "rt" in which:
     dt = (time.perf_counter() - t0) / 3
     print("rtpghi S=%d n=%d  %.2f ms per step  %.1f kframes/s  (real-time budget %.1f ms)" % (
         S, nfr, dt * 1e3, S * nfr / dt / 1e3, nfr * 256 / 44.1))
+if "sizes" in which:
+    # round-2 additions away from n_fft 1024: register core at 4096 / 2048 / 512, mixed radix, long-row banded walk,
+    # one-kernel MelSpectrogram at 2048 / 512, stacked representations in place
+    def plain(name, t):
+        print("%-44s %8.3f ms" % (name, t), flush=True)
+    del X
+    for n_fft, hop in ((4096, 1024), (2048, 512), (512, 128), (400, 160)):
+        st = A.STFT(n_fft=n_fft, hop_length=hop).to(dev)
+        Xn = st(x)
+        plain("STFT(%d, hop %d) forward" % (n_fft, hop), timeit(lambda: st(x), n=5, warm=2))
+        plain("STFT(%d, hop %d) invert" % (n_fft, hop), timeit(lambda: st.invert(Xn), n=5, warm=2))
+        if n_fft >= 2048:
+            for nm in (128, None):
+                mgn = A.Magnitude(n_fft=n_fft, n_mels=nm, mode=None).to(dev)
+                yn = mgn(Xn)
+                plain("Magnitude(n_fft %d, %s mels) forward" % (n_fft, nm or "n_fft/2+1"), timeit(lambda: mgn(Xn), n=5, warm=2))
+                plain("Magnitude(n_fft %d, %s mels) invert" % (n_fft, nm or "n_fft/2+1"), timeit(lambda: mgn.invert(yn), n=5, warm=2))
+                del yn
+        if n_fft in (2048, 512):
+            mf = A.MFCC(n_fft=n_fft, hop_length=hop, n_mels=128 if n_fft == 2048 else 64).to(dev)
+            plain("MFCC(%d, hop %d) mel spectrogram, one kernel" % (n_fft, hop), timeit(lambda: mf(x), n=5, warm=2))
+        if n_fft == 2048:
+            for name, tr in (("Cartesian", A.Cartesian()), ("PolarIF", A.PolarIF(magnitude_args={"mode": "bipolar", "n_fft": 2048}))):
+                tr = tr.to(dev)
+                tr.scale_data(Xn)
+                yy = tr(Xn)
+                plain("%s @ n_fft 2048 forward" % name, timeit(lambda: tr(Xn), n=5, warm=2))
+                plain("%s @ n_fft 2048 invert" % name, timeit(lambda: tr.invert(yy), n=5, warm=2))
+                del yy
+        del Xn
