@@ -107,6 +107,7 @@ __global__ void affine_kernel(const float* __restrict__ x, long long n, const fl
 // Cartesian (reference spectral_repr.py:403-428): normalise(x.real) and normalise(x.imag) stacked on dim -2, and back.
 // One pass over the spectrum either way: (rows, F) complex64 <-> (rows, 2, F) float32.  A null offset: no Normalize
 // on that half.
+// (row, bin) of the flat element index are carried along the grid stride (one division per thread, not per element)
 template <bool WIDE>
 __global__ __launch_bounds__(256) void cartesian_pack_kernel(const float2* __restrict__ x, long long rows, int F,
                                                              const float* re_off, const float* re_sc, const float* im_off,
@@ -115,12 +116,21 @@ __global__ __launch_bounds__(256) void cartesian_pack_kernel(const float2* __res
   const float io = im_off ? *im_off : 0.f, is = im_off ? *im_sc : 1.f;
   using Idx = typename std::conditional<WIDE, unsigned long long, unsigned>::type;
   const Idx total = (Idx)rows * (Idx)F;
-  for (Idx i = (Idx)blockIdx.x * 256 + threadIdx.x; i < total; i += (Idx)gridDim.x * 256) {
-    const Idx r = i / (Idx)F, f = i - r * (Idx)F;
+  const Idx stride = (Idx)gridDim.x * 256;
+  const Idx dr = stride / (Idx)F, df = stride - dr * (Idx)F;
+  Idx i = (Idx)blockIdx.x * 256 + threadIdx.x;
+  Idx r = i / (Idx)F, f = i - r * (Idx)F;
+  for (; i < total; i += stride) {
     const float2 v = x[i];
     float* dst = out + (2 * (unsigned long long)r) * F + f;
     dst[0] = re_off ? (v.x - ro) / rs : v.x;
     dst[F] = im_off ? (v.y - io) / is : v.y;
+    r += dr;
+    f += df;
+    if (f >= (Idx)F) {
+      f -= (Idx)F;
+      ++r;
+    }
   }
 }
 
@@ -133,11 +143,20 @@ __global__ __launch_bounds__(256) void cartesian_unpack_kernel(const float* __re
   const float io = im_off ? *im_off : 0.f, is = im_off ? *im_sc : 1.f;
   using Idx = typename std::conditional<WIDE, unsigned long long, unsigned>::type;
   const Idx total = (Idx)rows * (Idx)F;
-  for (Idx i = (Idx)blockIdx.x * 256 + threadIdx.x; i < total; i += (Idx)gridDim.x * 256) {
-    const Idx r = i / (Idx)F, f = i - r * (Idx)F;
+  const Idx stride = (Idx)gridDim.x * 256;
+  const Idx dr = stride / (Idx)F, df = stride - dr * (Idx)F;
+  Idx i = (Idx)blockIdx.x * 256 + threadIdx.x;
+  Idx r = i / (Idx)F, f = i - r * (Idx)F;
+  for (; i < total; i += stride) {
     const float* src = y + (2 * (unsigned long long)r) * F + f;
     const float re = src[0], im = src[F];
     out[i] = make_float2(re_off ? __fadd_rn(__fmul_rn(re, rs), ro) : re, im_off ? __fadd_rn(__fmul_rn(im, is), io) : im);
+    r += dr;
+    f += df;
+    if (f >= (Idx)F) {
+      f -= (Idx)F;
+      ++r;
+    }
   }
 }
 
