@@ -68,6 +68,37 @@ __device__ __forceinline__ float banded_contrast_inv(float v, int mode, float ep
   }
 }
 
+// sum over one band: `quads` steps of four bins, values at a[j], this lane's weights at w[64 j].  The reads of four steps
+// are issued before the first multiply-add (one LDS round trip per four steps instead of one per step); the chain of
+// multiply-adds keeps the order of the plain loop, so the result does not change.
+__device__ __forceinline__ float band_dot(const float4* a, const float4* w, int quads) {
+  float acc = 0.f;
+  int j = 0;
+  for (; j + 4 <= quads; j += 4) {
+    float4 av[4], wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[u] = a[j + u];
+      wv[u] = w[(j + u) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = fmaf(av[u].x, wv[u].x, acc);
+      acc = fmaf(av[u].y, wv[u].y, acc);
+      acc = fmaf(av[u].z, wv[u].z, acc);
+      acc = fmaf(av[u].w, wv[u].w, acc);
+    }
+  }
+  for (; j < quads; ++j) {
+    const float4 av = a[j], wv = w[j * 64];
+    acc = fmaf(av.x, wv.x, acc);
+    acc = fmaf(av.y, wv.y, acc);
+    acc = fmaf(av.z, wv.z, acc);
+    acc = fmaf(av.w, wv.w, acc);
+  }
+  return acc;
+}
+
 // NSEG >= ceil(K / 64) segments of 64 values per row; EXACT: NSEG == ceil(K / 64) (only the last segment can run
 // past the row's end).  CMW = 1 / 2: channel-major output (p.T > 0) of a bank with that many passes through a register
 // window -- every lane keeps the last eight frames of its filter(s) and stores them as 32 contiguous bytes of the
@@ -179,13 +210,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
         const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
         float acc = 0.f;
         const int quads = p.bank.pass_len[q] >> 2;
-        for (int j = 0; j < quads; ++j) {
-          const float4 av = a[j], wv = w[j * 64];
-          acc = fmaf(av.x, wv.x, acc);
-          acc = fmaf(av.y, wv.y, acc);
-          acc = fmaf(av.z, wv.z, acc);
-          acc = fmaf(av.w, wv.w, acc);
-        }
+        acc = band_dot(a, w, quads);
         w += quads * 64;
         acc = banded_contrast_fwd(acc, p.contrast, p.eps);
         if (p.offset) acc = (acc - off) / sc;
@@ -242,13 +267,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
       const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
       float acc = 0.f;
       const int quads = p.bank.pass_len[q] >> 2;
-      for (int j = 0; j < quads; ++j) {
-        const float4 av = a[j], wv = w[j * 64];
-        acc = fmaf(av.x, wv.x, acc);
-        acc = fmaf(av.y, wv.y, acc);
-        acc = fmaf(av.z, wv.z, acc);
-        acc = fmaf(av.w, wv.w, acc);
-      }
+      acc = band_dot(a, w, quads);
       w += quads * 64;
       if (f >= 0) {
         if (!p.inverse) {

@@ -365,7 +365,22 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
         // two running sums (even / odd bins of each pair) on packed multiply-adds, joined at the end
         v2f acc2 = {0.f, 0.f};
         const int quads = p.bank.pass_len[q] >> 2;       // wave-uniform; shorter bands multiply zeros
-        for (int j = 0; j < quads; ++j) {
+        int j = 0;
+        // four steps' reads issued before the first multiply-add: one LDS round trip per four steps, not per step
+        for (; j + 4 <= quads; j += 4) {
+          float4 av[4], wv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            av[u] = a[j + u];
+            wv[u] = w[(j + u) * 64];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc2 = __builtin_elementwise_fma((v2f){av[u].x, av[u].y}, (v2f){wv[u].x, wv[u].y}, acc2);
+            acc2 = __builtin_elementwise_fma((v2f){av[u].z, av[u].w}, (v2f){wv[u].z, wv[u].w}, acc2);
+          }
+        }
+        for (; j < quads; ++j) {
           const float4 av = a[j], wv = w[j * 64];
           acc2 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, acc2);
           acc2 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, acc2);

@@ -502,7 +502,21 @@ __global__ __launch_bounds__(64 * W2K, 2) void stft2048_mel_kernel(P2kMel p) {
         const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
         v2f acc2 = {0.f, 0.f};
         const int quads = p.bank.pass_len[q] >> 2;
-        for (int j = 0; j < quads; ++j) {
+        int j = 0;
+        for (; j + 4 <= quads; j += 4) {          // four steps' reads ahead of the multiply-adds
+          float4 av[4], wv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            av[u] = a[j + u];
+            wv[u] = w[(j + u) * 64];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc2 = __builtin_elementwise_fma((v2f){av[u].x, av[u].y}, (v2f){wv[u].x, wv[u].y}, acc2);
+            acc2 = __builtin_elementwise_fma((v2f){av[u].z, av[u].w}, (v2f){wv[u].z, wv[u].w}, acc2);
+          }
+        }
+        for (; j < quads; ++j) {
           const float4 av = a[j], wv = w[j * 64];
           acc2 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, acc2);
           acc2 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, acc2);
@@ -546,7 +560,21 @@ __global__ __launch_bounds__(64 * W2K, 2) void stft2048_mel_kernel(P2kMel p) {
         const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
         v2f acc2 = {0.f, 0.f};
         const int quads = p.bank.pass_len[q] >> 2;
-        for (int j = 0; j < quads; ++j) {
+        int j = 0;
+        for (; j + 4 <= quads; j += 4) {          // four steps' reads ahead of the multiply-adds
+          float4 av[4], wv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            av[u] = a[j + u];
+            wv[u] = w[(j + u) * 64];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc2 = __builtin_elementwise_fma((v2f){av[u].x, av[u].y}, (v2f){wv[u].x, wv[u].y}, acc2);
+            acc2 = __builtin_elementwise_fma((v2f){av[u].z, av[u].w}, (v2f){wv[u].z, wv[u].w}, acc2);
+          }
+        }
+        for (; j < quads; ++j) {
           const float4 av = a[j], wv = w[j * 64];
           acc2 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, acc2);
           acc2 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, acc2);
