@@ -190,7 +190,10 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
 // p.phase_ld -- Compose(STFT + Polar) in one kernel, the complex spectrum never reaches HBM.
 // HS: hop in 128-sample register slots (1, 2 = the reference's default hop 256, 4): the window slides HS slots per
 // frame and HS new segments are fetched.
-template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2>
+// SP (row-major features of a one- or two-pass bank -- the 128-mel bank of the headline step): the passes are
+// unrolled and what a lane needs for them (its filter, where its walk starts, the walk's length) is read once per
+// run instead of once per pass and frame.
+template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2, int SP = 0>
 __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
   constexpr int H = 128 * HS;
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
@@ -230,6 +233,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
   if (t1 > p.T) t1 = p.T;
   if (t0 >= t1) return;
 
+  int sp_f[SP > 0 ? SP : 1], sp_start[SP > 0 ? SP : 1], sp_quads[SP > 0 ? SP : 1];
+  if constexpr (SP > 0) {
+#pragma unroll
+    for (int q = 0; q < SP; ++q) {
+      sp_f[q] = lane_tab[(SP + q) * 64 + lane];
+      sp_start[q] = lane_tab[q * 64 + lane];
+      sp_quads[q] = p.bank.pass_len[q] >> 2;
+    }
+  }
   Twiddles tw_regs;
   if (!TWLDS) load_twiddles<false>(tw_regs, p.tw, lane);
   const LdsTwiddles<false> tw_lds = {tab, lane};
@@ -359,12 +371,12 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
       // the channel-major register window `cmrow`, a compile-time row of `cm`)
       auto one_pass = [&](int q, auto cmsel) {
         constexpr int CMROW = decltype(cmsel)::value;     // -1: no register window
-        const int f = lane_tab[(p.bank.n_passes + q) * 64 + lane];
+        const int f = SP > 0 ? sp_f[q] : lane_tab[(p.bank.n_passes + q) * 64 + lane];
         // one ds_read_b128 of magnitudes and one of weights per four multiply-adds
-        const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
+        const float4* a = reinterpret_cast<const float4*>(absrow + (SP > 0 ? sp_start[q] : lane_tab[q * 64 + lane]));
         // two running sums (even / odd bins of each pair) on packed multiply-adds, joined at the end
         v2f acc2 = {0.f, 0.f};
-        const int quads = p.bank.pass_len[q] >> 2;       // wave-uniform; shorter bands multiply zeros
+        const int quads = SP > 0 ? sp_quads[q] : p.bank.pass_len[q] >> 2;       // wave-uniform; shorter bands multiply zeros
         int j = 0;
         // four steps' reads issued before the first multiply-add: one LDS round trip per four steps, not per step
         for (; j + 4 <= quads; j += 4) {
@@ -421,6 +433,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
       if constexpr (CMBUF >= 1) {            // the launcher picks CMBUF == n_passes (1 or 2)
         one_pass(0, std::integral_constant<int, 0>());
         if constexpr (CMBUF >= 2) one_pass(1, std::integral_constant<int, 1>());
+      } else if constexpr (SP >= 1) {        // likewise SP == n_passes
+        one_pass(0, std::integral_constant<int, -1>());
+        if constexpr (SP >= 2) one_pass(1, std::integral_constant<int, -1>());
       } else {
         for (int q = 0; q < p.bank.n_passes; ++q) one_pass(q, std::integral_constant<int, -1>());
       }
@@ -932,6 +947,13 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     else if (!out && polar) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, true>;
     else if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true>;
     else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true> : stft1024_h256_fwd_kernel<false, 1, 8, true>;
+    // row-major features of a one- / two-pass bank at the default hop: passes unrolled, lane constants hoisted
+    if (hop == 256 && !polar && !phase && !feat_channel_major && bank->n_passes <= 2) {
+      if (bank->n_passes == 1)
+        kernel = out ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 1> : stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 1>;
+      else
+        kernel = out ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2> : stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 2>;
+    }
     if (hop == 128) {
       if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 1>;
       else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true, 0, false, 1> : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 1>;
