@@ -547,7 +547,10 @@ __device__ __forceinline__ void load_raw(const InvParams& p, long long f, int la
   const f32x2* row = reinterpret_cast<const f32x2*>(p.X + f * F);
 #pragma unroll
   for (int m = 0; m < 8; ++m) q.d[m] = row[lane + 64 * m];
-  q.ny0 = row[512].x;  // broadcast load; only lane 0 uses it
+  // broadcast load; only lane 0 uses it.  A 4-byte load of the real part alone: as `row[512].x` it was an 8-byte
+  // load whose dead upper register the allocator handed to the next instruction at once -- a write-after-write
+  // hazard on a load just issued, i.e. `s_waitcnt vmcnt(0)` in the steady-state loop, draining both frames of lookahead.
+  q.ny0 = reinterpret_cast<const float*>(row + 512)[0];
 }
 __device__ __forceinline__ void load_raw(const InvParams& p, long long f, int lane, RawFrame<IN_POLAR>& q) {
   const float* mrow = p.mag + f * F;
