@@ -42,13 +42,12 @@ __device__ __forceinline__ float unwrap_correction(float jump) {
   // torch.remainder(x, 2 pi) = fmod, then + 2 pi when the result is negative.  Angles differ by less than 2 pi,
   // so x = jump + pi lies in (-pi, 3 pi): there fmod is x itself or x - 2 pi, and that subtraction is exact
   // (Sterbenz: 2 pi <= x <= 4 pi).  Anything else (arbitrary real input) takes the library fmod.
+  // As selects rather than a chain of branches: the same three cases, and the library call only outside
+  // (-2 pi, 4 pi) -- never for angles.  (Timing-neutral: the scans wait on their column walk, not on instructions.)
   const float x = jump + kPi;
-  float r;
-  if (x >= 0.0f && x < kTwoPi) r = x;
-  else if (x >= kTwoPi && x < 2.0f * kTwoPi) r = x - kTwoPi;
-  else if (x < 0.0f && x > -kTwoPi) r = x;
-  else r = fmodf(x, kTwoPi);
-  if (r != 0.0f && r < 0.0f) r += kTwoPi;
+  float r = (x >= kTwoPi) ? x - kTwoPi : x;
+  if (!(x > -kTwoPi && x < 2.0f * kTwoPi)) r = fmodf(x, kTwoPi);
+  r = (r < 0.0f) ? r + kTwoPi : r;
   float folded = r - kPi;
   if (folded == -kPi && jump > 0.0f) folded = kPi;
   const float corr = folded - jump;
