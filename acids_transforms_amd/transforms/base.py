@@ -70,6 +70,17 @@ class AudioTransform(nn.Module):
             raise NotImplementedError
         return {"inverted": self.invert(self.forward(x))}
 
+    @classmethod
+    def test_scripted_transform(cls, transform, batch_size=(2, 2), invert=True):
+        """The reference runs this on a TorchScript copy of the module; the HIP modules are not scriptable
+        (`scriptable = False`), the scenario itself -- silence in, forward, forward_with_time, invert -- is kept."""
+        x = torch.zeros(*batch_size, 44100, device="cuda")
+        time = torch.zeros(*batch_size, device="cuda")
+        x_t = transform.forward(x)
+        x_t, _ = transform.forward_with_time(x, time)
+        if invert:
+            transform.invert(x_t)
+
 
 class ComposeAudioTransform(AudioTransform):
     def __init__(self, transforms=(), sr=44100):

@@ -229,6 +229,17 @@ class Unsqueeze(AudioTransform):
         return x.squeeze(self.dim)
 
 
+    # self-test hooks: shape checks on a stand-in tensor (reference misc.py:37-52)
+    def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
+        stand_in = torch.zeros(2, 512, device=x.device)
+        assert self(stand_in).shape == (2, 1, 512)
+        return stand_in if time is None else (stand_in, time)
+
+    def test_inversion(self, x: torch.Tensor):
+        assert self.invert(self.forward(torch.zeros(2, 512, device=x.device))).shape == (2, 512)
+        return {}
+
+
 class Squeeze(AudioTransform):
     scriptable = False
     needs_scaling = False
@@ -253,6 +264,22 @@ class Squeeze(AudioTransform):
         return x.unsqueeze(self.dim)
 
 
+    # self-test hooks: full and partial squeeze of a stand-in tensor (reference misc.py:89-111)
+    def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
+        stand_in = torch.zeros(2, 1, 512, 1, device=x.device)
+        self.dim = None
+        assert self(stand_in).shape == (2, 512)
+        self.dim = 1
+        assert self(stand_in).shape == (2, 512, 1)
+        return stand_in if time is None else (stand_in, time)
+
+    def test_inversion(self, x: torch.Tensor):
+        self.dim = 1
+        stand_in = torch.zeros(2, 1, 512, 1, device=x.device)
+        assert self.invert(self.forward(stand_in)).shape == stand_in.shape
+        return {}
+
+
 class Transpose(AudioTransform):
     scriptable = False
     invertible = True
@@ -272,3 +299,13 @@ class Transpose(AudioTransform):
 
     def invert(self, x: torch.Tensor, inversion_mode: InversionEnumType = None, tolerance: float = 1.e-4):
         return self(x)
+
+    # self-test hooks (reference misc.py:140-154)
+    def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
+        y = self(torch.zeros(2, 128, 512, device=x.device))
+        assert y.shape == (2, 512, 128)
+        return y if time is None else (y, time)
+
+    def test_inversion(self, x: torch.Tensor):
+        assert self.invert(self.test_forward(x)).shape == (2, 128, 512)
+        return {}

@@ -215,3 +215,36 @@ class RealtimeDGT(DGT):
     def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
         out = self(frame(x, self._n_fft, self._hop, -1))
         return out if time is None else (out, None)
+
+    def _stream_round_trip(self, x: torch.Tensor, modes):
+        """The reference's streaming self-test (stft.py:324-351, dgt.py:480-509): the audio in chunks of 4 n_fft samples
+        through OverlapAdd -> this transform -> invert -> OverlapAdd.invert, once with the complex frames ("direct") and
+        once per spectrogram inversion mode from the magnitudes alone."""
+        from .oadd import OverlapAdd
+        n, h = self._n_fft, self._hop
+        outs = {}
+        for mode in [None] + list(modes):
+            self.reset(list(x.shape[:-1]))
+            oadd = OverlapAdd(n, h).to(x.device)
+            if mode is not None:
+                self.inversion_mode = mode
+            pieces = []
+            for chunk in x.split(4 * n, -1):
+                X = self(oadd(chunk))
+                frames = self.invert(X) if mode is None else self.invert(X.abs(), inversion_mode=mode)
+                pieces.append(oadd.invert(frames))
+            outs["direct" if mode is None else mode] = torch.cat(pieces, -1)
+        return outs
+
+    def test_inversion(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return self._stream_round_trip(x, self.get_inversion_modes())
+
+    @classmethod
+    def test_scripted_transform(cls, transform, invert: bool = True):
+        x = torch.zeros(2, 1, transform._n_fft, device="cuda")
+        transform.reset(list(x.shape[:-1]))
+        X = transform(x)
+        if invert:
+            transform.invert(X)
+            for mode in cls.get_inversion_modes():
+                transform.invert(X.abs(), inversion_mode=mode)

@@ -35,3 +35,21 @@ class OneHot(AudioTransform):
     def invert(self, x_onehot: torch.Tensor, inversion_mode: InversionEnumType = None,
                tolerance: float = 1.e-4) -> torch.Tensor:
         return ops.argmax_last(x_onehot)
+
+    # -- self-test hooks (reference misc.py:191-215): a random mu-law code vector stands in for the audio -------
+    def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
+        codes = torch.randint(0, 256, (2, 44100), device=x.device)
+        self.scale_data(codes)
+        return self(codes) if time is None else self.forward_with_time(codes, time)
+
+    def test_inversion(self, x: torch.Tensor):
+        self.invert(torch.randint(0, 256, tuple(x.shape), device=x.device).to(x.dtype))
+        return {}
+
+    @classmethod
+    def test_scripted_transform(cls, transform, invert: bool = True):
+        codes = torch.randint(0, 256, (2, 44100), device="cuda")
+        transform.scale_data(codes)
+        y = transform(codes)
+        if invert:
+            transform.invert(y)

@@ -76,5 +76,45 @@ class Normalize(AudioTransform):
         off, sc = self._params(x)
         return ops.affine(x, off, sc, inverse=True)
 
+    # -- self-test hooks (reference norm.py:49-97): every mode on 256-sample frames of the audio ------------
+    def _framed(self, x: torch.Tensor) -> torch.Tensor:
+        from ..utils.misc import frame
+        return frame(x, min(256, x.shape[-1]), min(64, x.shape[-1]), -1).contiguous()
+
+    def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
+        x = self._framed(x)
+        tolerance = torch.finfo(x.dtype).eps
+        x_norm = x
+        for mode in self.get_normalization_modes():
+            self.mode = mode
+            self.scale_data(x)
+            x_norm = self(x)
+            if mode == "unipolar":
+                assert float(x_norm.min()) == 0.0 and float(x_norm.max()) == 1.0
+            elif mode == "bipolar":
+                assert float(x_norm.min()) == -1.0 and float(x_norm.max()) == 1.0
+            else:
+                assert float(x_norm.mean()) < tolerance and float((x_norm.std() - 1).pow(2)) < tolerance
+        return x_norm if time is None else (x_norm, time)
+
+    def test_inversion(self, x: torch.Tensor, tolerance: float = None):
+        x = self._framed(x)
+        if tolerance is None:
+            tolerance = torch.finfo(x.dtype).eps
+        for mode in self.get_normalization_modes():
+            self.mode = mode
+            self.scale_data(x)
+            back = self.invert(self(x))
+            assert float((x.min() - back.min()).pow(2)) < tolerance and float((x.max() - back.max()).pow(2)) < tolerance
+        return {}
+
+    @classmethod
+    def test_scripted_transform(cls, transform, invert: bool = True):
+        x = torch.rand((5, 256), device="cuda")
+        transform.scale_data(x)
+        y = transform(x)
+        if invert:
+            transform.invert(y)
+
     def get_normalization_modes(self):
         return ["unipolar", "bipolar", "gaussian"]

@@ -67,6 +67,28 @@ class _Representation(AudioTransform):
         out = ops.affine(x, off, sc, inverse=True) if off is not None else x
         return out if self.keep_nyquist else _pad_last_bin(out)
 
+    # -- self-test hooks (the reference's test file drives every class through them) ------------------
+    def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
+        from ._selftest import stft_then
+        return stft_then(self, x, time)
+
+    @classmethod
+    def test_scripted_transform(cls, transform, invert: bool = True):
+        from ._selftest import random_spectrum
+        X = random_spectrum("cuda")
+        transform.scale_data(X)
+        y = transform(X)
+        if invert:
+            transform.invert(y)
+
+    def _round_trip(self, x: torch.Tensor, rebuild, n_fft: int = 1024, hop: int = 256):
+        """window-less STFT -> representation -> invert -> `rebuild(X, inverted)` -> window-less ISTFT."""
+        from ._selftest import rect_stft, rect_istft
+        X, batch_shape = rect_stft(x, n_fft, hop)
+        self.scale_data(X)
+        inv = self.invert(self(X))
+        return rect_istft(rebuild(X, inv), batch_shape, n_fft, hop)
+
 
 class Real(_Representation):
     def __repr__(self):
@@ -81,6 +103,10 @@ class Real(_Representation):
         off, sc = self._affine(x)
         re = x.real
         return ops.affine(re, off, sc) if off is not None else re
+
+    def test_inversion(self, x: torch.Tensor):
+        # the reference's scenario uses n_fft 512 / hop 128 for this class
+        return {"direct": self._round_trip(x, lambda X, re: torch.complex(re.contiguous(), X.imag.contiguous()), 512, 128)}
 
 
 class Imaginary(_Representation):
@@ -98,6 +124,9 @@ class Imaginary(_Representation):
             x = torch.zeros_like(x)
         return x if self.keep_nyquist else x[..., 1:]
 
+    def test_inversion(self, x: torch.Tensor):
+        return {"direct": self._round_trip(x, lambda X, im: torch.complex(X.real.contiguous(), im.contiguous()))}
+
 
 class Phase(_Representation):
     def __init__(self, sr: int = 44100, mode: Union[str, None] = None, keep_nyquist: bool = True, unwrap: bool = False):
@@ -114,6 +143,9 @@ class Phase(_Representation):
         off, sc = self._affine(x)
         y = ops.phase_scan(_as_complex(x), "unwrap" if self.unwrap else "angle", offset=off, scale=sc)
         return y if self.keep_nyquist else y[..., 1:]
+
+    def test_inversion(self, x: torch.Tensor):
+        return {"direct": self._round_trip(x, lambda X, ph: ops.polar_to_complex(X.abs(), ph))}
 
 
 class IF(_Representation):
@@ -171,6 +203,13 @@ class IF(_Representation):
         else:                                   # the reference integrates nothing for an unknown method
             out = ops.affine(x, off, sc, inverse=True) if off is not None else x
         return out if self.keep_nyquist else _pad_last_bin(out)
+
+    def test_inversion(self, x: torch.Tensor):
+        outs = {}
+        for method in self.get_if_methods():
+            self.method = method
+            outs[method] = self._round_trip(x, lambda X, ph: ops.polar_to_complex(X.abs(), ph))
+        return outs
 
 
 SpectralRepresentationType = Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]
@@ -254,6 +293,29 @@ class SpectralRepresentation(AudioTransform):
             return x[0], x[1]
         return x.select(self.stack, 0), x.select(self.stack, 1)
 
+    # -- self-test hooks (the reference's test file drives every class through them) ------------------
+    def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
+        from ._selftest import stft_then
+        return stft_then(self, x, time)
+
+    def _round_trip(self, x: torch.Tensor):
+        from ._selftest import rect_stft, rect_istft
+        X, batch_shape = rect_stft(x)
+        self.scale_data(X)
+        return rect_istft(self.invert(self(X)), batch_shape)
+
+    def test_inversion(self, x: torch.Tensor):
+        return {"direct": self._round_trip(x)}
+
+    @classmethod
+    def test_scripted_transform(cls, transform, invert: bool = True):
+        from ._selftest import random_spectrum
+        X = random_spectrum("cuda")
+        transform.scale_data(X)
+        y = transform(X)
+        if invert:
+            transform.invert(y)
+
     def _one_pass_invert(self, x):
         """The mirror image of `_one_pass`: de-normalise, invert the contrast, project through the banded inverse
         bank and attach exp(i phase), reading the stacked tensor once."""
@@ -324,6 +386,13 @@ class PolarIF(SpectralRepresentation):
     def __init__(self, sr: int = 44100, magnitude_args={"mode": "bipolar"}, phase_args={"mode": "bipolar"}, stack=-2,
                  keep_nyquist: bool = True):
         super().__init__(sr, Magnitude, IF, magnitude_args, phase_args, stack=stack, keep_nyquist=keep_nyquist)
+
+    def test_inversion(self, x: torch.Tensor):
+        outs = {}
+        for method in self.phase.get_if_methods():
+            self.phase.method = method
+            outs[method] = self._round_trip(x)
+        return outs
 
     def _in_place_parts(self, F: int, inverse: bool):
         """Banded bank of the magnitude half when both halves can work inside the stacked tensor: Magnitude over a

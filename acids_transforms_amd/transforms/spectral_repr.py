@@ -148,6 +148,28 @@ class Magnitude(AudioTransform):
             return X.reshape(batch_shape + X.shape[-2:]), feat
         return feat
 
+    # -- self-test hooks (the reference's test file drives every class through them) ------------------
+    def test_forward(self, x: torch.Tensor, time: torch.Tensor = None):
+        from ._selftest import stft_then
+        return stft_then(self, x, time)
+
+    def test_inversion(self, x: torch.Tensor):
+        """|X| through the representation and back, the phase kept aside, audio by the window-less ISTFT."""
+        from ._selftest import rect_stft, rect_istft
+        X, batch_shape = rect_stft(x)
+        self.scale_data(X)
+        mag = self.invert(self(X))
+        return {"direct": rect_istft(ops.polar_to_complex(mag, X.angle()), batch_shape)}
+
+    @classmethod
+    def test_scripted_transform(cls, transform, invert: bool = True):
+        from ._selftest import random_spectrum
+        X = random_spectrum("cuda")
+        transform.scale_data(X)
+        y = transform(X)
+        if invert:
+            transform.invert(y)
+
     def contrast(self, mag: torch.Tensor) -> torch.Tensor:
         ops.contrast_code(self.contrast_mode)   # TypeError on unknown modes, like the reference
         return ops.mag_pointwise(mag, self.contrast_mode, eps=self._eps)
