@@ -61,6 +61,7 @@ _SIGNATURES = {
     "at_pghi_gradients": [c_f, c_i64, c_int, c_int, c_flt, c_int, c_int, c_flt, c_f, c_f, c_f, c_f],
     "at_pghi_offline_workspace_bytes": [c_i64, c_int, c_int],
     "at_pghi_offline": [c_f, c_i64, c_int, c_int, c_flt, c_int, c_int, c_flt, c_flt, c_f, c_f, c_sz, c_f, c_f, c_f],
+    "at_pghi_integrate": [c_f, c_f, c_f, c_i64, c_int, c_int, c_flt, c_flt, c_f, c_f, c_sz, c_f, c_f, c_f],
     "at_pghi_rt_workspace_bytes": [c_int, c_int, c_int],
     "at_pghi_realtime": [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_flt, c_int, c_int, c_flt, c_flt, c_f, c_f, c_f,
                          c_f, c_sz, c_f],

@@ -1532,6 +1532,12 @@ int at_pghi_gradients(const float* mag, int64_t B, int T, int F, float gamma, in
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
+size_t at_pghi_offline_workspace_bytes(int64_t B, int T, int F);
+}
+static int pghi_integrate_launch(float* spec, const float* tg, const float* fg, int64_t B, int T, int F, float tol, float abstol,
+                                 float* phase, at_hip::HeapItem* heap, int64_t* npops_or_null, int32_t* order_or_null,
+                                 hipStream_t s);
+extern "C" {
 size_t at_pghi_offline_workspace_bytes(int64_t B, int T, int F) {
   const size_t n = (size_t)T * (size_t)F;
   // spec + tgradw + fgradw (fp32) + heap (8 B entries, n + 2)
@@ -1557,6 +1563,32 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
   hipStream_t s = (hipStream_t)stream;
   GradParams g = {mag, spec, tg, fg, (long long)B, T, F, n_fft, hop, gamma, abstol};
   hipLaunchKernelGGL(pghi_grad_offline_kernel, dim3(grid1d((long long)B * T * F)), dim3(256), 0, s, g);
+  return pghi_integrate_launch(spec, tg, fg, B, T, F, tol, abstol, phase, heap, npops_or_null, order_or_null, s);
+}
+
+int at_pghi_integrate(const float* mag, const float* tgradw, const float* fgradw, int64_t B, int T, int F, float tol,
+                      float abstol, float* phase, void* workspace, size_t workspace_bytes, int64_t* npops_or_null,
+                      int32_t* order_or_null, void* stream) {
+  if (B < 0 || T <= 0 || F <= 0) return AT_EINVAL;
+  if (B == 0) return AT_OK;
+  if (!mag || !tgradw || !fgradw || !phase) return AT_EINVAL;
+  if ((long long)T * F > (1LL << 26) - 64) return AT_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < at_pghi_offline_workspace_bytes(B, T, F)) return AT_EWORKSPACE;
+  const size_t n = (size_t)T * (size_t)F;
+  float* spec = (float*)workspace;                       // the integration marks visited bins in its own copy
+  uintptr_t hp = ((uintptr_t)(spec + 3 * (size_t)B * n) + 15) & ~(uintptr_t)15;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyAsync(spec, mag, sizeof(float) * (size_t)B * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return AT_ELAUNCH;
+  return pghi_integrate_launch(spec, tgradw, fgradw, B, T, F, tol, abstol, phase, (HeapItem*)hp, npops_or_null, order_or_null, s);
+}
+
+}  // extern "C"
+
+// the heap integration proper: spec (B, T, F) is consumed (visited bins are overwritten), the gradients are read only
+static int pghi_integrate_launch(float* spec, const float* tg, const float* fg, int64_t B, int T, int F, float tol, float abstol,
+                                 float* phase, at_hip::HeapItem* heap, int64_t* npops_or_null, int32_t* order_or_null,
+                                 hipStream_t s) {
+  using namespace at_hip;
   static const int prof = [] { const char* e = getenv("ACIDS_PGHI_PROF"); return (e && e[0] == '1') ? 1 : 0; }();
   // LDS share of the heap: as much as fits while every clip of the batch can still be resident (160 KB per CU)
   int cus = 256;
@@ -1611,6 +1643,8 @@ int at_pghi_offline(const float* mag, int64_t B, int T, int F, float gamma, int 
   }
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
+
+extern "C" {
 
 size_t at_pghi_rt_workspace_bytes(int S, int n, int F) {
   const size_t per = (size_t)(n + 2) * (size_t)F;

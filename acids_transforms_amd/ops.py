@@ -334,6 +334,23 @@ def pghi_offline(mag, gamma, n_fft, hop, tol, eps=1.1920929e-07, debug=False):
     return (phase, npops, order) if debug else phase
 
 
+def pghi_integrate(mag, tgradw, fgradw, tol, abstol=1.1920929e-07, debug=False):
+    """DGT.perform_hgi: heap integration of (B, T, F) magnitudes along caller-supplied gradients -> phase (B, T, F);
+    debug=True also returns (npops, order).  `mag` is left untouched."""
+    require_device(mag, tgradw, fgradw)
+    mag, tgradw, fgradw = _f32c(mag), _f32c(tgradw), _f32c(fgradw)
+    assert tgradw.shape == mag.shape and fgradw.shape == mag.shape
+    B, T, F = mag.shape
+    phase = torch.empty_like(mag)
+    wsb = lib().at_pghi_offline_workspace_bytes(B, T, F)
+    ws = _workspace(wsb, mag.device)
+    npops = torch.zeros(B, dtype=torch.int64, device=mag.device) if debug else None
+    order = torch.full((B, T * F), -1, dtype=torch.int32, device=mag.device) if debug else None
+    check(lib().at_pghi_integrate(ptr(mag), ptr(tgradw), ptr(fgradw), B, T, F, tol, abstol, ptr(phase), ptr(ws), wsb,
+                                  ptr(npops), ptr(order), stream_ptr()), "at_pghi_integrate")
+    return (phase, npops, order) if debug else phase
+
+
 def pghi_realtime(mag_hist, mag, prev_phase, noise, gamma, n_fft, hop, tol, eps=1.1920929e-07, debug=False):
     """streaming PGHI for S streams: (S,2,F), (S,n,F), (S,F), (S,n,F) -> phase (S,n,F)."""
     require_device(mag, mag_hist, prev_phase, noise)

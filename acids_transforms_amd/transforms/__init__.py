@@ -1,7 +1,7 @@
 from .base import (AudioTransform, ComposeAudioTransform, NotInvertibleError, InversionEnumType,
                    apply_transform_to_list, apply_invert_transform_to_list)
 from .stft import STFT, RealtimeSTFT
-from .dgt import DGT, RealtimeDGT
+from .dgt import DGT, RealtimeDGT, DGT_INVERSION_MODES
 from .norm import Normalize
 from .spectral_repr import Magnitude
 from .phase_repr import Real, Imaginary, Phase, IF, SpectralRepresentation, Cartesian, Polar, PolarIF
@@ -12,6 +12,6 @@ from .misc import OneHot
 from .channels import Mono, Stereo, MidSide, Window, Squeeze, Unsqueeze, Transpose
 
 __all__ = ["AudioTransform", "ComposeAudioTransform", "NotInvertibleError", "InversionEnumType",
-           "apply_transform_to_list", "apply_invert_transform_to_list", "STFT", "RealtimeSTFT", "DGT", "RealtimeDGT",
+           "apply_transform_to_list", "apply_invert_transform_to_list", "STFT", "RealtimeSTFT", "DGT", "RealtimeDGT", "DGT_INVERSION_MODES",
            "Normalize", "Magnitude", "Real", "Imaginary", "Phase", "IF", "SpectralRepresentation", "Cartesian", "Polar",
            "PolarIF", "MFCC", "OverlapAdd", "MuLaw", "OneHot", "Mono", "Stereo", "MidSide", "Window", "Squeeze", "Unsqueeze", "Transpose"]

@@ -9,6 +9,7 @@ canonical dual (:114-123); PGHI runs in pghi.hip with the reference's exact
 binary-heap order (utils/heapq.py).
 """
 import math
+from enum import Enum
 from typing import Dict, List, Union
 
 import torch
@@ -18,7 +19,14 @@ from ..utils.misc import frame, reshape_batches
 from .base import AudioTransform, InversionEnumType
 from .stft import RealtimeSTFT, STFT
 
-__all__ = ["DGT", "RealtimeDGT"]
+__all__ = ["DGT", "RealtimeDGT", "DGT_INVERSION_MODES"]
+
+
+class DGT_INVERSION_MODES(Enum):
+    KEEP_INPUT = 0
+    GRIFFIN_LIM = 1
+    PGHI = 2
+    RANDOM = 3
 
 
 class DGT(STFT):
@@ -94,6 +102,17 @@ class DGT(STFT):
         phase = ops.pghi_offline(m, self._hostf("gamma"), self._n_fft, self._hop, tol, self._hostf("eps"))
         return phase[0] if squeeze else phase
 
+    def perform_hgi(self, X: torch.Tensor, tgradw: torch.Tensor, fgradw: torch.Tensor, abstol: float = 1e-7,
+                    tol: float = 1.e-2) -> torch.Tensor:
+        """The heap integration on its own (reference dgt.py:168-220): phase of a (T, F) -- or (B, T, F) -- magnitude
+        array along the given gradients, `pghi(mag)` being `perform_hgi(clamp(mag, eps), *modgabphasegrad(mag), eps,
+        tolerance)`.  Unlike the reference's method this one does not overwrite X."""
+        self._follow(X)
+        squeeze = X.dim() == 2
+        args = [t.unsqueeze(0) if squeeze else t for t in (X, tgradw, fgradw)]
+        phase = ops.pghi_integrate(args[0], args[1], args[2], float(tol), float(abstol))
+        return phase[0] if squeeze else phase
+
     def modgabphasegrad(self, mag: torch.Tensor):
         """(tgradw, fgradw) of a clamped (T, F) magnitude array (reference dgt.py:222-236)."""
         self._follow(mag)
@@ -140,6 +159,16 @@ class RealtimeDGT(DGT):
         F = self._n_fft // 2 + 1
         self.hgi_mag_buffer = torch.zeros(torch.Size(self.batch_size) + torch.Size([2, F]), device=dev)
         self.hgi_phase_buffer = torch.zeros(torch.Size(self.batch_size) + torch.Size([F]), device=dev)
+
+    def update_buffers(self, x: torch.Tensor) -> None:
+        """Carry the last two magnitude rows and the last phase row of a complex chunk (..., n, F) into the PGHI state
+        (reference dgt.py:330-336)."""
+        self._follow(x)
+        if x.shape[-2] > 1:
+            self.hgi_mag_buffer = x[..., -2:, :].abs()
+        else:
+            self.hgi_mag_buffer = torch.stack([self.hgi_mag_buffer[..., 1, :], x[..., -1, :].abs()], -2)
+        self.hgi_phase_buffer = ops.angle(x[..., -1, :].contiguous())
 
     def _get_gamma(self) -> torch.Tensor:
         # the streaming variant keeps lambda itself (reference dgt.py:373-374)

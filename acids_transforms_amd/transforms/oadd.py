@@ -91,6 +91,40 @@ class OverlapAdd(AudioTransform):
         return out.reshape(tuple(lead) + (out.shape[-1],))
 
 
+    # -- the reference's state helpers (oadd.py:33-67), for callers that drive the buffers themselves ------------
+    def get_input_buffer(self, x: torch.Tensor) -> torch.Tensor:
+        """History to put in front of chunk `x` (zeros on a new batch shape); the last (n_fft/hop - 1) hops of `x`
+        become the next history."""
+        self._follow(x)
+        lead = x.shape[:-1]
+        hist = self.input_buffer.clone() if self.input_buffer.shape[:-1] == lead else \
+            torch.zeros(tuple(lead) + (self._keep,), device=x.device, dtype=x.dtype)
+        self.input_buffer = x[..., -self._keep:]
+        return hist
+
+    def get_output_buffer(self, x: torch.Tensor) -> torch.Tensor:
+        """Carried overlap-add tail for frames `x` (..., n, n_fft): zeros on a new batch shape."""
+        self._follow(x)
+        lead = x.shape[:-2]
+        if self.output_buffer.shape[:-1] == lead:
+            return self.output_buffer.clone()
+        return torch.zeros(tuple(lead) + (self._keep,), device=x.device, dtype=x.dtype)
+
+    def _forward_without_update(self, x: torch.Tensor) -> torch.Tensor:
+        return frame(x, self._n_fft, self._hop, dim=-1)
+
+    def _invert_without_update(self, x: torch.Tensor, inversion_mode: Union[str, None] = None,
+                               tolerance: Union[float, None] = None) -> torch.Tensor:
+        """Overlap-add of frames (..., n, n_fft) with no carried state: n * hop + n_fft samples, each frame scaled by
+        2 / overlap and the sum divided by the gain compensation."""
+        self._follow(x)
+        lead = x.shape[:-2]
+        x3 = x.reshape((-1,) + tuple(x.shape[-2:])).contiguous()
+        out, tail = ops.oadd_invert(x3, None, self._n_fft, self._hop, self._keep, self.gain_compensation)
+        full = torch.cat([out, tail / self.gain_compensation, torch.zeros(out.shape[0], self._hop, device=x.device)], -1)
+        return full.reshape(tuple(lead) + (full.shape[-1],))
+
+
 def _row_strides(lead):
     """Contiguous strides (in rows) of the leading batch dims."""
     out, acc = [], 1

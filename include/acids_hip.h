@@ -185,6 +185,14 @@ int at_pghi_offline(const float *mag, int64_t B, int T, int F, float gamma, int 
                     float abstol, float *phase, void *workspace, size_t workspace_bytes, int64_t *npops_or_null,
                     int32_t *order_or_null, void *stream);
 
+/* DGT.perform_hgi (dgt.py:168-220) on its own: the heap integration of B (T,F) magnitude arrays along gradients the
+ * CALLER supplies (tgradw is applied along the bin axis, fgradw along the frame axis, as the reference's method uses
+ * them), same pop order, same threshold rule (bins below tol * max are never visited).  mag is not modified (the
+ * reference integrates in its argument); workspace as for at_pghi_offline. */
+int at_pghi_integrate(const float *mag, const float *tgradw, const float *fgradw, int64_t B, int T, int F, float tol,
+                      float abstol, float *phase, void *workspace, size_t workspace_bytes, int64_t *npops_or_null,
+                      int32_t *order_or_null, void *stream);
+
 size_t at_pghi_rt_workspace_bytes(int S, int n, int F);
 
 /* RealtimeDGT.pghi (dgt.py:338-354, 378-466) for S streams: mag_hist (S,2,F),

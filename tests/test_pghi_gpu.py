@@ -280,3 +280,47 @@ def test_winner_bit_kernel_stays_exact(dev):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "24 cases ok" in r.stdout and "identical order" in r.stdout
+
+
+def test_perform_hgi_with_caller_supplied_gradients(dev):
+    """DGT.perform_hgi (dgt.py:168-220) as its own entry point: fed modgabphasegrad's gradients it reproduces pghi()
+    pop for pop; fed other gradients it integrates those (the pop order depends on the magnitudes alone), and the
+    magnitude array passed in stays untouched."""
+    g = torch.Generator().manual_seed(77)
+    d = A.DGT(n_fft=128, hop_length=32).to(dev)
+    mags = (torch.randn(3, 19, 65, generator=g) ** 2 + torch.randn(3, 19, 65, generator=g) ** 2).sqrt().to(dev)
+    eps, tol = float(d.eps), float(d.tolerance)
+    clamped = torch.clamp(mags, min=eps)
+    tg, fg = d.modgabphasegrad(clamped)
+    keep = clamped.clone()
+    ph = d.perform_hgi(clamped, tg, fg, eps, tol)
+    assert torch.equal(clamped, keep)
+    assert torch.equal(ph, d.pghi(mags))
+    assert torch.equal(d.perform_hgi(clamped[1], tg[1], fg[1], eps, tol), ph[1])          # 2-D form
+    # other gradients, same magnitudes: same pops, phases follow the new gradients (zero gradients -> zero phase)
+    z = torch.zeros_like(tg)
+    p0, n0, o0 = ops.pghi_integrate(clamped, z, z, tol, eps, debug=True)
+    p1, n1, o1 = ops.pghi_integrate(clamped, tg, fg, tol, eps, debug=True)
+    assert torch.equal(n0, n1) and torch.equal(o0, o1) and float(p0.abs().max()) == 0.0
+    for b in range(3):
+        r = O.pghi_offline(mags[b].cpu(), 128, 32, want_order=True)
+        assert int(n1[b]) == len(r["order"])
+        assert np.array_equal(cpu(o1[b][:len(r["order"])]), r["order"][:, 0] * 65 + r["order"][:, 1])
+
+
+def test_overlap_add_state_helpers(dev):
+    """get_input_buffer / get_output_buffer / _forward_without_update / _invert_without_update (reference
+    oadd.py:33-67): the stateless pair reproduces what forward / invert do on a fresh module."""
+    oa = A.OverlapAdd(1024, 256).to(dev)
+    x = torch.randn(2, 4096, device=dev)
+    fr = oa._forward_without_update(x)
+    assert fr.shape[-1] == 1024
+    full = oa._invert_without_update(fr)
+    assert full.shape == (2, fr.shape[-2] * 256 + 1024)
+    fresh = A.OverlapAdd(1024, 256).to(dev)
+    y = fresh.invert(fr)                                   # zeros carried in: the same sums, minus the tail
+    assert torch.allclose(full[..., :y.shape[-1]], y, rtol=0, atol=1e-6)
+    h0 = oa.get_input_buffer(x)
+    assert h0.shape == (2, 768) and float(h0.abs().max()) == 0.0
+    assert torch.equal(oa.get_input_buffer(x), x[..., -768:])
+    assert oa.get_output_buffer(fr).shape == (2, 768)
