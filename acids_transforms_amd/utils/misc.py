@@ -1,5 +1,5 @@
 """Shape helpers shared by the transforms (reference utils/misc.py:138-178)."""
-__all__ = ["pad", "frame", "n_frames", "reshape_batches", "unwrap", "fdiff_forward", "fdiff_backward", "fdiff_central",
+__all__ = ["pad", "frame", "n_frames", "reshape_batches", "get_fft_idx", "deriv", "unwrap", "fdiff_forward", "fdiff_backward", "fdiff_central",
            "fint_forward", "fint_backward", "fint_central"]
 from typing import Tuple
 
@@ -98,3 +98,31 @@ def fint_backward(x):
 def fint_central(x):
     """The reference's two interleaved recurrences, quirks included (see phase_repr.hip)."""
     return _fint(x, "central")
+
+
+def get_fft_idx(L: int) -> torch.Tensor:
+    """Signed bin indices of an L-point FFT in storage order: 0 .. ceil(L/2) (the Nyquist bin counted as positive), then
+    the negative ones (reference utils/misc.py:130-135)."""
+    if L % 2 == 0:
+        return torch.cat([torch.arange(0, L // 2 + 1), torch.arange(-L // 2 + 1, 0)])
+    return torch.cat([torch.arange(0, (L + 1) // 2), torch.arange(-(L - 1) // 2, 0)])
+
+
+def deriv(mag: torch.Tensor, order=2) -> torch.Tensor:
+    """Derivative of a periodic signal sampled on [0, 1) along dim 0 (ltfat's pderiv; reference utils/misc.py:107-127):
+    centred differences of order 2 or 4, or the spectral derivative for order = inf.  (The reference's spectral branch
+    cannot run -- it calls Tensor.transpose() without arguments and never applies the bin index; this is the operation
+    it documents.  No transform of the reference calls `deriv`.)"""
+    assert order in (2, 4, float("inf")), "order must be 2, 4 or inf"
+    L = mag.shape[0]
+    if order == 2:
+        return L * (mag.roll(-1, 0) - mag.roll(1, 0)) / 2
+    if order == 4:
+        return L * (-mag.roll(-2, 0) + 8 * mag.roll(-1, 0) - 8 * mag.roll(1, 0) + mag.roll(2, 0)) / 12
+    n = get_fft_idx(L).to(mag.device)
+    if L % 2 == 0:
+        n = n.clone()
+        n[L // 2] = 0                     # the Nyquist bin of a real signal has no derivative of its own
+    n = n.reshape((L,) + (1,) * (mag.dim() - 1))
+    out = 2 * torch.pi * torch.fft.ifft(1j * n * torch.fft.fft(mag, dim=0), dim=0)
+    return out if mag.is_complex() else out.real

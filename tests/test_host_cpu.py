@@ -229,3 +229,17 @@ def test_channel_stage_matches_reference(golden):
     with pytest.raises(A.NotInvertibleError):
         A.Squeeze().invert(st)
     assert not A.Squeeze().invertible and A.Squeeze(dim=1).invertible
+
+
+def test_periodic_derivative_helpers():
+    """utils.misc.deriv / get_fft_idx (reference utils/misc.py:107-135): derivative of sin(2 pi k t) on [0, 1)."""
+    import math
+    from acids_transforms_amd.utils.misc import deriv, get_fft_idx
+    assert get_fft_idx(6).tolist() == [0, 1, 2, 3, -2, -1] and get_fft_idx(5).tolist() == [0, 1, 2, -2, -1]
+    L, k = 256, 3
+    t = torch.arange(L, dtype=torch.float64) / L
+    x = torch.sin(2 * math.pi * k * t).unsqueeze(1)
+    want = 2 * math.pi * k * torch.cos(2 * math.pi * k * t).unsqueeze(1)
+    assert float((deriv(x, float("inf")) - want).abs().max()) < 1e-9
+    assert float((deriv(x, 4) - want).abs().max()) < 2e-4 * float(want.abs().max())
+    assert float((deriv(x, 2) - want).abs().max()) < 2e-3 * float(want.abs().max())
