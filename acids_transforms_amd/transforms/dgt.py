@@ -92,11 +92,12 @@ class DGT(STFT):
             raise ValueError("inversion mode %s not valid." % self.inversion_mode)
         return self._istft(mag=x, phase=phase)
 
-    def pghi(self, mag: torch.Tensor, tolerance=None) -> torch.Tensor:
+    def pghi(self, mag: torch.Tensor, tolerance=1.e-4) -> torch.Tensor:
         """Phase for a (T, F) or (B, T, F) magnitude array (reference dgt.py:156-162,
-        applied clip by clip as at :137-141).  The caller's tensor is not modified."""
+        applied clip by clip as at :137-141; `invert` passes the module's own tolerance, a direct call defaults to
+        the reference's 1e-4).  The caller's tensor is not modified."""
         self._follow(mag)
-        tol = self._hostf("tolerance") if (tolerance is None or tolerance is self.tolerance) else float(tolerance)
+        tol = self._hostf("tolerance") if tolerance is self.tolerance else float(tolerance)
         squeeze = mag.dim() == 2
         m = mag.unsqueeze(0) if squeeze else mag
         phase = ops.pghi_offline(m, self._hostf("gamma"), self._n_fft, self._hop, tol, self._hostf("eps"))
@@ -224,12 +225,12 @@ class RealtimeDGT(DGT):
         from .sinebank import sinebank_realtime
         return sinebank_realtime(self, x_fft, self.inv_window[:self._n_fft] if windowed else None)
 
-    def pghi(self, mag: torch.Tensor, tolerance=None, noise: torch.Tensor = None):
+    def pghi(self, mag: torch.Tensor, tolerance=1e-6, noise: torch.Tensor = None):
         """Streaming PGHI (reference dgt.py:338-354, 378-466) for (..., n, F) magnitudes using the
         two-frame magnitude history and the previous phase.  `noise` (same shape as mag)
         overrides the standard-normal draws used for bins at or below the tolerance."""
         self._follow(mag)
-        tol = self._hostf("tolerance") if (tolerance is None or tolerance is self.tolerance) else float(tolerance)
+        tol = self._hostf("tolerance") if tolerance is self.tolerance else float(tolerance)   # direct calls: 1e-6 (dgt.py:338)
         m, batch_shape = reshape_batches(mag, -2)
         hist, _ = reshape_batches(self.hgi_mag_buffer, -2)
         prev, _ = reshape_batches(self.hgi_phase_buffer, -1)

@@ -51,7 +51,7 @@ def test_offline_golden_exact_order(golden, dev, case):
     assert np.array_equal(ph == 0, ref == 0)                                # (i) visited mask
     assert np.all(np.abs(ph - ref) <= phase_tol(ref))                       # (iii)
     assert np.array_equal(cpu(mag), g[case + "_mag"])                       # caller's tensor untouched
-    assert np.array_equal(cpu(d.pghi(mag)), ph)                             # module entry point, 2-D input
+    assert np.array_equal(cpu(d.pghi(mag, d.tolerance)), ph)                             # module entry point, 2-D input
 
 
 def test_offline_batch_matches_per_clip_oracle(dev):
@@ -113,7 +113,7 @@ def test_offline_real_audio_golden(golden, dev):
     x = T_(g["x"]).to(dev)
     X = d(x)
     # (iii) on the reference's own magnitudes (a round trip through the GPU DGT may flip near-ties)
-    ph = cpu(d.pghi(T_(g["mag_dgt"]).to(dev)))
+    ph = cpu(d.pghi(T_(g["mag_dgt"]).to(dev), d.tolerance))
     ref = g["phase_pghi"]
     assert np.array_equal(ph == 0, ref == 0)
     assert np.all(np.abs(ph - ref) <= phase_tol(ref, base=5e-3, ulps=16))
@@ -140,7 +140,7 @@ def test_realtime_kernel_golden(golden, dev, tag):
     ref = g[tag + "_phase"]
     assert np.all(np.abs(cpu(ph) - ref) <= phase_tol(ref, base=2e-3, ulps=16))
     # module entry point with explicit noise
-    ph2 = rt.pghi(mag, noise=T_(g[tag + "_noise"]).to(dev))
+    ph2 = rt.pghi(mag, rt.tolerance, noise=T_(g[tag + "_noise"]).to(dev))
     assert np.array_equal(cpu(ph2), cpu(ph))
 
 
@@ -155,7 +155,7 @@ def test_realtime_stream_golden(golden, dev, tag):
         noise = T_(g["%s_noise_%d" % (tag, c)]).to(dev)
         if list(mag.shape[:-2]) != list(rt.hgi_mag_buffer.shape[:-2]):
             rt.reset(mag.shape[:-2])
-        ph = rt.pghi(mag, noise=noise)
+        ph = rt.pghi(mag, rt.tolerance, noise=noise)
         frames, rt.hgi_mag_buffer, rt.hgi_phase_buffer = ops.rt_polar_irfft_update(
             mag, ph, rt.inv_window[:n], n, rt.hgi_mag_buffer)
         ref = g["%s_yframes_%d" % (tag, c)]
@@ -295,7 +295,7 @@ def test_perform_hgi_with_caller_supplied_gradients(dev):
     keep = clamped.clone()
     ph = d.perform_hgi(clamped, tg, fg, eps, tol)
     assert torch.equal(clamped, keep)
-    assert torch.equal(ph, d.pghi(mags))
+    assert torch.equal(ph, d.pghi(mags, d.tolerance))
     assert torch.equal(d.perform_hgi(clamped[1], tg[1], fg[1], eps, tol), ph[1])          # 2-D form
     # other gradients, same magnitudes: same pops, phases follow the new gradients (zero gradients -> zero phase)
     z = torch.zeros_like(tg)
@@ -324,3 +324,17 @@ def test_overlap_add_state_helpers(dev):
     assert h0.shape == (2, 768) and float(h0.abs().max()) == 0.0
     assert torch.equal(oa.get_input_buffer(x), x[..., -768:])
     assert oa.get_output_buffer(fr).shape == (2, 768)
+
+
+def test_direct_pghi_calls_use_the_reference_defaults(dev):
+    """DGT.pghi(mag) defaults to tolerance 1e-4 and RealtimeDGT.pghi(mag) to 1e-6 (dgt.py:156, 338) -- `invert` is what
+    passes the module's own `tolerance` (1e-2)."""
+    g = torch.Generator().manual_seed(5)
+    d = A.DGT(n_fft=128, hop_length=32).to(dev)
+    mag = (torch.rand(17, 65, generator=g) ** 4).to(dev)
+    assert torch.equal(d.pghi(mag), d.pghi(mag, 1e-4))
+    assert not torch.equal(d.pghi(mag), d.pghi(mag, d.tolerance))          # more bins integrated at the tighter tolerance
+    rt = A.RealtimeDGT(n_fft=128, hop_length=32, batch_size=[1]).to(dev)
+    m = mag[:4].unsqueeze(0)
+    z = torch.zeros_like(m)
+    assert torch.equal(rt.pghi(m, noise=z), rt.pghi(m, 1e-6, noise=z))

@@ -113,7 +113,7 @@ def test_graph_captured_streaming_session_matches_modules(dev):
         y = sess.step(xc).clone()
         fr = oa(xc)
         mag = rt(fr).abs()
-        ph = rt.pghi(mag, noise=torch.zeros_like(mag))
+        ph = rt.pghi(mag, rt.tolerance, noise=torch.zeros_like(mag))
         from acids_transforms_amd import ops
         frames, rt.hgi_mag_buffer, rt.hgi_phase_buffer = ops.rt_polar_irfft_update(mag, ph, rt.inv_window[:n], n,
                                                                                     rt.hgi_mag_buffer)
@@ -185,7 +185,7 @@ def test_per_hop_rtpghi_golden(golden, dev, tag):
         ref = g["%s_yframes_%d" % (tag, j)]
         # (1) module, one frame per call, on the golden magnitudes
         mag = T_(mag_ref).to(dev)
-        ph = rt.pghi(mag, noise=noise)
+        ph = rt.pghi(mag, rt.tolerance, noise=noise)
         frames = ops.irfft_frames(None, rt.inv_window[:n], n, mag=mag, phase=ph)
         ops.rt_update_buffers_(mag, ph, rt.hgi_mag_buffer, rt.hgi_phase_buffer)
         assert _snr_db(cpu(frames), ref) > 40.0, (j, _snr_db(cpu(frames), ref))
@@ -230,7 +230,7 @@ def test_streaming_session_256_streams(dev, C):
         fr = oa(xc)
         X = rt(fr)
         mag = X.abs()
-        ph = rt.pghi(mag, noise=torch.zeros_like(mag))
+        ph = rt.pghi(mag, rt.tolerance, noise=torch.zeros_like(mag))
         frames = ops.irfft_frames(None, rt.inv_window[:n], n, mag=mag, phase=ph)
         ops.rt_update_buffers_(mag, ph, rt.hgi_mag_buffer, rt.hgi_phase_buffer)
         yr = oi.invert(frames)

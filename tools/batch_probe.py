@@ -32,5 +32,5 @@ for B in (1, 2, 8, 32, 128, 512, 1024):
     f = timeit(lambda: mag.forward_fused(stft, x, return_spectrum=True))
     i = timeit(lambda: stft.invert(X))
     m = dgt(x).abs()
-    p = timeit(lambda: dgt.pghi(m), n=2, warm=1) if B <= 128 else float("nan")
+    p = timeit(lambda: dgt.pghi(m, dgt.tolerance), n=2, warm=1) if B <= 128 else float("nan")
     print("B %5d: fused forward %8.1f us  (%6.2f us/clip)   inverse %8.1f us   pghi %10.1f us" % (B, f, f / B, i, p), flush=True)

@@ -124,7 +124,7 @@ if "pghi" in which:
     torch.cuda.synchronize()
     import time
     t0 = time.perf_counter()
-    d.pghi(mg)
+    d.pghi(mg, d.tolerance)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("pghi B=%d  %.3f s  %.1f kframes/s  %.2f Mpops/s" % (nb, dt, nb * T / dt / 1e3, nb * T * 513 / dt / 1e6))

@@ -18,7 +18,7 @@ if B > 0:
     m = d(x).abs()
     del x
     for _ in range(int(os.environ.get("PGHI_REPS", "2"))):
-        ph = d.pghi(m)
+        ph = d.pghi(m, d.tolerance)
     torch.cuda.synchronize()
     del m, ph
 for C in (256, 1024):

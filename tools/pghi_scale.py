@@ -27,15 +27,15 @@ def mags(B):
 
 
 m = mags(256)
-d.pghi(m)
+d.pghi(m, d.tolerance)
 torch.cuda.synchronize()
 del m
 for B in sizes:
     m = mags(B)
-    d.pghi(m)                      # first touch of this size's workspace (tens of GB) is not part of the figure
+    d.pghi(m, d.tolerance)                      # first touch of this size's workspace (tens of GB) is not part of the figure
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ph = d.pghi(m)
+    ph = d.pghi(m, d.tolerance)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("clips %6d  %7.3f s  %8.1f kframes/s  %7.1f Mpops/s  (%.1f GB allocated)" % (

@@ -13,10 +13,10 @@ d = A.DGT().to(dev)
 for tag, x in (("tonal", synth_tonal(B, CLIP_LEN, device=dev)),
                ("decaying noise", torch.randn(B, CLIP_LEN, device=dev) * torch.exp(-8.0 * torch.arange(CLIP_LEN, device=dev) / 44100.0))):
     m = d(x).abs()
-    d.pghi(m)
+    d.pghi(m, d.tolerance)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ph = d.pghi(m)
+    ph = d.pghi(m, d.tolerance)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     thr = m.amax(dim=(1, 2), keepdim=True) * float(d.tolerance)
