@@ -695,10 +695,53 @@ def g15():
     save("g15_rtpghi_per_hop", **out)
 
 
+# --------------------------------------------------------------------------
+# G16: FFT sizes other than the default (round 2: register-core kernels at 2048 / 512 / 4096 / 256, mixed-radix kernels
+# at 400 / 1000 and the odd size 441, the long-row banded walk): the reference's own outputs for STFT / DGT forward and
+# inverse, a small PGHI inversion at n_fft 400, and Magnitude at n_fft 2048 (bank recorded: it comes from the shim).
+# --------------------------------------------------------------------------
+def g16():
+    out = {}
+    sizes = [(2048, 512), (512, 128), (4096, 1024), (256, 64), (400, 160), (1000, 250), (441, 147)]
+    out["sizes"] = np.array(sizes)
+    for (n, h) in sizes:
+        L = 3 * n + 37
+        x = torch.stack([sig_noise((L,), n) * 0.3, sig_tonal(L)])
+        out["x_%d" % n] = x
+        for name, cls in [("stft", at.STFT), ("dgt", at.DGT)]:
+            m = cls(n_fft=n, hop_length=h)
+            X = m(x)
+            key = "%s_%d" % (name, n)
+            out["X_" + key] = X
+            out["y_" + key] = m.invert(X)
+            out["window_" + key] = m.window[:n]
+            out["inv_window_" + key] = m.inv_window[:n]
+    d = at.DGT(n_fft=400, hop_length=100)
+    xs = sig_tonal(1500)[None]
+    mag = d(xs).abs()
+    out["pghi_mag_400"] = mag
+    out["pghi_phase_400"] = d.pghi(mag[0], d.tolerance)
+    out["pghi_y_400"] = d.invert(mag, inversion_mode="pghi")
+    mg = at.Magnitude(n_fft=2048)
+    g = torch.Generator().manual_seed(2048)
+    Xm = (torch.randn(2, 5, 1025, generator=g) * torch.exp(2j * np.pi * torch.rand(2, 5, 1025, generator=g))).to(torch.complex64)
+    mg.scale_data(Xm)
+    ym = mg(Xm)
+    out["mag2048_X"] = Xm
+    out["mag2048_y"] = ym
+    out["mag2048_inv"] = mg.invert(ym)
+    nz = mg.mel_bank[0].nonzero()
+    out["mag2048_bank_idx"] = nz.to(torch.int32)
+    out["mag2048_bank_val"] = mg.mel_bank[0][nz[:, 0], nz[:, 1]]
+    out["mag2048_offset"] = mg.norm.offset
+    out["mag2048_scale"] = mg.norm.scale
+    save("g16_other_sizes", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13,
-             "g14": g14, "g15": g15}
+             "g14": g14, "g15": g15, "g16": g16}
     for w in which:
         print("==", w)
         table[w]()

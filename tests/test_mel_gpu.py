@@ -173,6 +173,26 @@ def test_mfcc_melspectrogram(dev):
     assert rel_max(cpu(c), cr.numpy()) < 2e-5
 
 
+def test_magnitude_n_fft_2048_golden(golden, dev):
+    """G16: the reference's Magnitude(n_fft=2048) -- 1025 filters, its own bank (built through the shim: one bin per
+    filter), log1p + unipolar statistics -- forward and invert through the long-row banded walk (17 passes)."""
+    g = golden("g16_other_sizes")
+    X = torch.from_numpy(g["mag2048_X"]).to(dev)
+    bank = torch.zeros(1025, 1025)
+    idx = torch.from_numpy(g["mag2048_bank_idx"]).long()
+    bank[idx[:, 0], idx[:, 1]] = torch.from_numpy(g["mag2048_bank_val"])
+    mg = A.Magnitude(n_fft=2048)
+    mg._set_bank(bank)
+    mg = mg.to(dev)
+    mg.scale_data(X)
+    assert abs(float(mg.norm.offset) - float(g["mag2048_offset"])) < 1e-6
+    assert abs(float(mg.norm.scale) - float(g["mag2048_scale"])) < 1e-5
+    assert mg._band_of("mel_bank") is not None and mg._band_of("mel_bank").n_passes == 17
+    y = mg(X)
+    assert rel_max(cpu(y), g["mag2048_y"]) < TOL
+    assert rel_max(cpu(mg.invert(torch.from_numpy(g["mag2048_y"]).to(dev))), g["mag2048_inv"]) < 2e-5
+
+
 @pytest.mark.parametrize("n,h,n_mels,L", [(2048, 512, 128, 30000), (512, 128, 64, 9001), (4096, 1024, 128, 50000),
                                           (256, 64, 40, 5000), (2048, 512, 80, 2048 * 3 + 17), (400, 160, 40, 16000),
                                           (1024, 100, 128, 7000), (2048, 300, 200, 20001), (2048, 2048, 40, 9000),

@@ -58,6 +58,45 @@ def test_stft_istft_other_hops(golden, name, h):
     assert y.shape == g["y_" + k].shape and rel_max(y.numpy(), g["y_" + k]) < 3e-6
 
 
+@pytest.mark.parametrize("n,h", [(2048, 512), (512, 128), (4096, 1024), (256, 64), (400, 160), (1000, 250), (441, 147)])
+def test_stft_istft_other_sizes(golden, n, h):
+    """G16: the reference itself at other FFT sizes -- powers of two, 400 / 1000, the odd size 441 -- windows, dual
+    windows, forward and inverse of STFT and DGT."""
+    g = golden("g16_other_sizes")
+    x = T(g["x_%d" % n])
+    for name in ("stft", "dgt"):
+        w = O.hann_window(n) if name == "stft" else O.gauss_window(n)
+        iw = w if name == "stft" else O.dual_window(w, n, h)
+        k = "%s_%d" % (name, n)
+        assert rel_max(w.numpy(), g["window_" + k]) < 1e-6 and rel_max(iw.numpy(), g["inv_window_" + k]) < 1e-6
+        X = O.stft_forward(x, w, n, h)
+        assert X.shape == g["X_" + k].shape and rel_max(X.numpy(), g["X_" + k]) < 3e-6
+        y = O.istft(X, iw, n, h)
+        assert y.shape == g["y_" + k].shape and rel_max(y.numpy(), g["y_" + k]) < 3e-6
+
+
+def test_pghi_and_magnitude_other_sizes(golden):
+    """G16: the reference's PGHI at n_fft 400 (phase and reconstruction) and Magnitude at n_fft 2048 (its own bank)."""
+    g = golden("g16_other_sizes")
+    mag = g["pghi_mag_400"][0]
+    r = O.pghi_offline(mag, 400, 100)
+    ref = g["pghi_phase_400"]
+    assert np.array_equal(r["phase"] == 0, ref == 0)
+    assert np.all(np.abs(r["phase"] - ref) <= 1e-3 + 1e-5 * np.abs(ref))
+    bank = torch.zeros(1025, 1025)              # the bank the reference built (through the shim: one bin per filter)
+    idx = torch.from_numpy(g["mag2048_bank_idx"]).long()
+    bank[idx[:, 0], idx[:, 1]] = T(g["mag2048_bank_val"])
+    fwd, inv = O.magnitude_banks(bank)
+    X = T(g["mag2048_X"])
+    off, sc = float(g["mag2048_offset"]), float(g["mag2048_scale"])
+    o2, s2 = O.magnitude_scale_stats(X, "log1p", "unipolar")
+    assert abs(float(o2) - off) < 1e-6 and abs(float(s2) - sc) < 1e-5
+    y = O.magnitude_forward(X, fwd, "log1p", off, sc)
+    assert rel_max(y.numpy(), g["mag2048_y"]) < 3e-6
+    yi = O.magnitude_invert(T(g["mag2048_y"]), inv, "log1p", off, sc)
+    assert rel_max(yi.numpy(), g["mag2048_inv"]) < 1e-5
+
+
 def test_stft_multidim_and_time(golden):
     g = golden("g2_stft")
     x = T(g["x_md"])

@@ -278,6 +278,33 @@ def test_other_hops_golden(golden, dev, name, h):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,h", [(2048, 512), (512, 128), (4096, 1024), (256, 64), (400, 160), (1000, 250), (441, 147)])
+def test_other_sizes_golden(golden, dev, n, h):
+    """G16: outputs of the reference itself at other FFT sizes (register-core kernels at 2048 / 512 / 4096 / 256, mixed-radix
+    kernels at 400 / 1000 and the odd 441): windows, forward and complex inverse of STFT and DGT; at n_fft 400 a PGHI
+    phase (same visited set, same values) and its reconstruction."""
+    g = golden("g16_other_sizes")
+    x = torch.from_numpy(g["x_%d" % n]).to(dev)
+    for name, cls in (("stft", A.STFT), ("dgt", A.DGT)):
+        m = cls(n_fft=n, hop_length=h).to(dev)
+        k = "%s_%d" % (name, n)
+        assert rel_max(cpu(m.window[:n]), g["window_" + k]) < 1e-6 and rel_max(cpu(m.inv_window[:n]), g["inv_window_" + k]) < 1e-6
+        X = m(x)
+        assert X.shape == g["X_" + k].shape and rel_max(cpu(X), g["X_" + k]) < TOL
+        y = m.invert(torch.from_numpy(g["X_" + k]).to(dev))
+        assert y.shape == g["y_" + k].shape and rel_max(cpu(y), g["y_" + k]) < TOL
+    if n == 400:
+        d = A.DGT(n_fft=400, hop_length=100).to(dev)
+        mag = torch.from_numpy(g["pghi_mag_400"]).to(dev)
+        ph, ref = cpu(d.pghi(mag[0], d.tolerance)), g["pghi_phase_400"]
+        assert np.array_equal(ph == 0, ref == 0)
+        assert np.all(np.abs(ph - ref) <= 1e-3 + 8 * np.spacing(np.abs(ref).astype(np.float32)) + 1e-5 * np.abs(ref))
+        yp, yref = cpu(d.invert(mag, inversion_mode="pghi")), g["pghi_y_400"]
+        assert yp.shape == yref.shape
+        assert 10 * np.log10((yref ** 2).sum() / max(((yp - yref) ** 2).sum(), 1e-30)) >= 40.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hop", [128, 256, 512])
 def test_griffinlim_update_fused_into_the_inverse(dev, hop):
     """at_istft_griffinlim == at_istft(at_griffinlim_update(...)): the phase update taken while the inverse kernel
