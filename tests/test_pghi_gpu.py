@@ -52,6 +52,12 @@ def test_offline_golden_exact_order(golden, dev, case):
     assert np.all(np.abs(ph - ref) <= phase_tol(ref))                       # (iii)
     assert np.array_equal(cpu(mag), g[case + "_mag"])                       # caller's tensor untouched
     assert np.array_equal(cpu(d.pghi(mag, d.tolerance)), ph)                             # module entry point, 2-D input
+    # perform_hgi on its own, fed the REFERENCE's gradients (dgt.py:168-220): same pops, the reference's phases
+    mc = torch.clamp(mag, float(d.eps))
+    ph2, np2, or2 = ops.pghi_integrate(mc.unsqueeze(0), T_(g[case + "_tgradw"]).to(dev).unsqueeze(0),
+                                       T_(g[case + "_fgradw"]).to(dev).unsqueeze(0), float(d.tolerance), float(d.eps), debug=True)
+    assert int(np2[0]) == len(ref_order) and np.array_equal(cpu(or2[0][:len(ref_order)]), got)
+    assert np.all(np.abs(cpu(ph2[0]) - ref) <= phase_tol(ref))
 
 
 def test_offline_batch_matches_per_clip_oracle(dev):
