@@ -738,10 +738,59 @@ def g16():
     save("g16_other_sizes", **out)
 
 
+# --------------------------------------------------------------------------
+# G17: the streaming classes at other FFT sizes: OverlapAdd -> RealtimeSTFT / RealtimeDGT forward and complex inverse
+# over two chunks (n_fft 512, 2048: register-core frame kernels; 400: mixed-radix), and RealtimeDGT.pghi on a fixed state
+# at n_fft 512 and 400 (noise recorded, torch.empty -> zeros as in G5).
+# --------------------------------------------------------------------------
+def g17():
+    out = {}
+    for (n, h, chunk) in [(512, 128, 2048), (2048, 512, 4096), (400, 100, 1600)]:
+        key = "%d" % n
+        x = sig_noise((2, 2 * chunk), 170 + n) * 0.3
+        oa, oi, od = at.OverlapAdd(n, h), at.OverlapAdd(n, h), at.OverlapAdd(n, h)
+        rs = at.RealtimeSTFT(n_fft=n, hop_length=h)
+        rd = at.RealtimeDGT(n_fft=n, hop_length=h)
+        out["x_" + key] = x
+        out["params_" + key] = np.array([n, h, chunk])
+        for c in range(2):
+            fr = oa(x[:, c * chunk:(c + 1) * chunk])
+            X = rs(fr)
+            yf = rs.invert(X)
+            Xd = rd(fr)
+            ydf = rd.invert(Xd)
+            out["frames_%s_%d" % (key, c)] = fr
+            out["X_%s_%d" % (key, c)] = X
+            out["yframes_%s_%d" % (key, c)] = yf
+            out["y_%s_%d" % (key, c)] = oi.invert(yf)
+            out["Xd_%s_%d" % (key, c)] = Xd
+            out["ydframes_%s_%d" % (key, c)] = ydf
+            out["yd_%s_%d" % (key, c)] = od.invert(ydf)
+    for tag, n, h, nfr, seed in [("k512", 512, 128, 4, 171), ("k400", 400, 100, 3, 172)]:
+        torch.manual_seed(seed)
+        F = n // 2 + 1
+        S = 2
+        rt = at.RealtimeDGT(n_fft=n, hop_length=h, batch_size=[S])
+        rt.hgi_mag_buffer = mags_for(S * 2, F, "noise", seed).reshape(S, 2, F)
+        rt.hgi_phase_buffer = (torch.rand(S, F) * 2 - 1) * np.pi
+        mag = mags_for(S * nfr, F, "noise", seed + 1).reshape(S, nfr, F)
+        mag[1] = mags_for(nfr, F, "sparse", seed + 2)
+        out[tag + "_magbuf"] = rt.hgi_mag_buffer.clone()
+        out[tag + "_phasebuf"] = rt.hgi_phase_buffer.clone()
+        out[tag + "_mag"] = mag.clone()
+        out[tag + "_params"] = np.array([n, h])
+        noise = []
+        with rt_patches(noise):
+            phase = rt.pghi(mag, rt.tolerance)
+        out[tag + "_noise"] = torch.stack(noise)
+        out[tag + "_phase"] = phase
+    save("g17_streaming_sizes", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13,
-             "g14": g14, "g15": g15, "g16": g16}
+             "g14": g14, "g15": g15, "g16": g16, "g17": g17}
     for w in which:
         print("==", w)
         table[w]()

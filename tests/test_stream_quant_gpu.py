@@ -285,3 +285,44 @@ def test_streaming_session_draws_its_noise_in_the_kernels(dev):
     torch.manual_seed(5)
     again = StreamingDGTSession(S, C, device=dev, random_phase_below_tolerance=True, use_graph=False)
     assert torch.equal(again.rng_state[:2], sess.rng_state[:2])    # torch.manual_seed governs the session's seed
+
+
+@pytest.mark.parametrize("n", [512, 2048, 400])
+def test_streaming_classes_at_other_sizes_golden(golden, dev, n):
+    """G17: the reference's OverlapAdd -> RealtimeSTFT / RealtimeDGT -> invert -> OverlapAdd.invert over two chunks at
+    n_fft 512 and 2048 (register-core frame kernels) and 400 (mixed-radix kernels): frames bit for bit, spectra,
+    synthesised frames and audio at 1e-5."""
+    g = golden("g17_streaming_sizes")
+    n_, h, chunk = [int(v) for v in g["params_%d" % n]]
+    x = torch.from_numpy(g["x_%d" % n]).to(dev)
+    oa, oi, od = A.OverlapAdd(n, h).to(dev), A.OverlapAdd(n, h).to(dev), A.OverlapAdd(n, h).to(dev)
+    rs, rd = A.RealtimeSTFT(n_fft=n, hop_length=h).to(dev), A.RealtimeDGT(n_fft=n, hop_length=h).to(dev)
+    for c in range(2):
+        fr = oa(x[:, c * chunk:(c + 1) * chunk])
+        assert np.array_equal(fr.cpu().numpy(), g["frames_%d_%d" % (n, c)])
+        X = rs(fr)
+        assert rel_max(X.cpu().numpy(), g["X_%d_%d" % (n, c)]) < 1e-5
+        yf = rs.invert(torch.from_numpy(g["X_%d_%d" % (n, c)]).to(dev))
+        assert rel_max(yf.cpu().numpy(), g["yframes_%d_%d" % (n, c)]) < 1e-5
+        assert rel_max(oi.invert(torch.from_numpy(g["yframes_%d_%d" % (n, c)]).to(dev)).cpu().numpy(), g["y_%d_%d" % (n, c)]) < 1e-5
+        Xd = rd(fr)
+        assert rel_max(Xd.cpu().numpy(), g["Xd_%d_%d" % (n, c)]) < 1e-5
+        ydf = rd.invert(torch.from_numpy(g["Xd_%d_%d" % (n, c)]).to(dev))
+        assert rel_max(ydf.cpu().numpy(), g["ydframes_%d_%d" % (n, c)]) < 1e-5
+        assert rel_max(od.invert(torch.from_numpy(g["ydframes_%d_%d" % (n, c)]).to(dev)).cpu().numpy(), g["yd_%d_%d" % (n, c)]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["k512", "k400"])
+def test_realtime_pghi_at_other_sizes_golden(golden, dev, tag):
+    """G17: RealtimeDGT.pghi on a fixed state at n_fft 512 and 400 (257 / 201 bins per frame), the reference's recorded
+    noise fed back in."""
+    g = golden("g17_streaming_sizes")
+    n, h = [int(v) for v in g[tag + "_params"]]
+    rt = A.RealtimeDGT(n_fft=n, hop_length=h, batch_size=[2]).to(dev)
+    rt.hgi_mag_buffer = torch.from_numpy(g[tag + "_magbuf"]).to(dev)
+    rt.hgi_phase_buffer = torch.from_numpy(g[tag + "_phasebuf"]).to(dev)
+    mag = torch.from_numpy(g[tag + "_mag"]).to(dev)
+    ph = rt.pghi(mag, rt.tolerance, noise=torch.from_numpy(g[tag + "_noise"]).to(dev)).cpu().numpy()
+    ref = g[tag + "_phase"]
+    tol = 2e-3 + 16 * np.spacing(np.abs(ref).astype(np.float32)) + 1e-5 * np.abs(ref)
+    assert np.all(np.abs(ph - ref) <= tol)
