@@ -374,3 +374,37 @@ def test_sinebank(golden):
         for i in range(2):
             y, now = O.sinebank_realtime(t("chunks")[i], 44100, 128, 32, t(name + "_phase"), now)
             assert torch.allclose(y * t(name + "_inv_window"), t(name)[i], rtol=1e-5, atol=2e-6), (name, i)
+
+
+@pytest.mark.parametrize("n", [512, 2048, 400])
+def test_streaming_classes_other_sizes(golden, n):
+    """G17: the reference's streaming chain at n_fft 512 / 2048 / 400 against the oracle's restatement."""
+    g = golden("g17_streaming_sizes")
+    n_, h, chunk = [int(v) for v in g["params_%d" % n]]
+    x = T(g["x_%d" % n])
+    fa, fi, fd = O.OverlapAddState(n, h), O.OverlapAddState(n, h), O.OverlapAddState(n, h)
+    w, gw = O.hann_window(n), O.gauss_window(n)
+    dw = O.dual_window(gw, n, h)
+    for c in range(2):
+        fr = fa.forward(x[:, c * chunk:(c + 1) * chunk])
+        assert np.array_equal(fr.numpy(), g["frames_%d_%d" % (n, c)])
+        X = O.rt_forward(fr, w)
+        assert rel_max(X.numpy(), g["X_%d_%d" % (n, c)]) < 3e-6
+        yf = O.rt_invert(X, w)
+        assert rel_max(yf.numpy(), g["yframes_%d_%d" % (n, c)]) < 3e-6
+        assert rel_max(fi.invert(yf).numpy(), g["y_%d_%d" % (n, c)]) < 3e-6
+        Xd = O.rt_forward(fr, gw)
+        assert rel_max(Xd.numpy(), g["Xd_%d_%d" % (n, c)]) < 3e-6
+        ydf = O.rt_invert(Xd, dw)
+        assert np.allclose(ydf.numpy(), g["ydframes_%d_%d" % (n, c)], rtol=3e-6, atol=3e-7)
+        assert rel_max(fd.invert(ydf).numpy(), g["yd_%d_%d" % (n, c)]) < 3e-6
+
+
+@pytest.mark.parametrize("tag", ["k512", "k400"])
+def test_rtpghi_kernel_other_sizes(golden, tag):
+    g = golden("g17_streaming_sizes")
+    n, h = [int(v) for v in g[tag + "_params"]]
+    r = O.pghi_realtime(g[tag + "_magbuf"], g[tag + "_mag"], g[tag + "_phasebuf"], g[tag + "_noise"], n, h)
+    ref = g[tag + "_phase"]
+    tol_arr = 2e-3 + 16 * np.spacing(np.abs(ref).astype(np.float32)) + 1e-5 * np.abs(ref)
+    assert np.all(np.abs(r["phase"] - ref) <= tol_arr)
