@@ -135,3 +135,34 @@ def test_operands_on_mixed_devices_are_rejected_and_other_device_works(dev):
     assert X1.device == d1 and torch.cuda.current_device() == 0
     assert torch.equal(X1.cpu(), s0(x).cpu())
     assert torch.equal(s1.invert(X1).cpu(), s0.invert(s0(x)).cpu())
+
+
+def test_empty_and_single_row_inputs_of_the_round_two_paths(dev):
+    """Empty batches and single frames through the entry points added in round 2: the one-kernel MelSpectrogram at
+    n_fft 2048 / 512, Cartesian / PolarIF in place, the long-row banded walk, the mixed-radix sizes, perform_hgi."""
+    for n, h in ((2048, 512), (512, 128)):
+        mf = A.MFCC(n_fft=n, hop_length=h, n_mels=64).to(dev)
+        y = mf(torch.zeros(0, 4 * n, device=dev))
+        assert y.shape == (0, 64, 1 + 4 * n // h)
+        one = mf(torch.randn(1, n // 2 + 1, device=dev))          # shortest clip torch.stft accepts: three frames at hop n/4
+        assert one.shape[0] == 1 and one.shape[1] == 64 and bool(torch.isfinite(one).all())
+    X0 = torch.zeros(0, 7, 1025, dtype=torch.complex64, device=dev)
+    X1 = torch.randn(1, 1, 1025, dtype=torch.complex64, device=dev)
+    car = A.Cartesian(real_args={"mode": None}, imag_args={"mode": None}).to(dev)
+    assert car(X0).shape == (0, 7, 2, 1025) and car.invert(car(X0)).shape == (0, 7, 1025)
+    assert torch.equal(car.invert(car(X1)), X1)
+    mg = A.Magnitude(n_fft=2048, mode=None).to(dev)
+    assert mg(X0).shape == (0, 7, 1025) and mg.invert(mg(X0)).shape == (0, 7, 1025)
+    assert mg(X1).shape == (1, 1, 1025)
+    pif = A.PolarIF(magnitude_args={"mode": None, "n_fft": 2048}, phase_args={"mode": None}).to(dev)
+    assert pif(X0).shape == (0, 7, 2, 1025)
+    y1 = pif(X1)                                                   # a single frame: forward differences of nothing
+    assert y1.shape == (1, 1, 2, 1025) and pif.invert(y1).shape == (1, 1, 1025)
+    st = A.STFT(n_fft=400, hop_length=160).to(dev)
+    Xe = st(torch.zeros(0, 1600, device=dev))
+    assert Xe.shape == (0, 11, 201) and st.invert(Xe).shape == (0, 1600)
+    d = A.DGT(n_fft=128, hop_length=32).to(dev)
+    z = torch.zeros(0, 5, 65, device=dev)
+    assert d.perform_hgi(z, z, z).shape == (0, 5, 65)
+    m1 = torch.rand(1, 65, device=dev) + 0.1
+    assert d.perform_hgi(m1, torch.zeros_like(m1), torch.zeros_like(m1)).shape == (1, 65)
