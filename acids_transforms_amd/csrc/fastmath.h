@@ -31,4 +31,15 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {
   return copysignf(r, y);
 }
 
+// sin / cos of a phase of any size (unwrapped phases reach 1e5 rad): reduced in fp64 to revolutions in [-0.5, 0.5]
+// (exact to ~1e-16), then the hardware v_sin_f32 / v_cos_f32 (they take revolutions; abs error ~1e-6, inside the 1e-5
+// bar of everything that multiplies a magnitude by them).  ~10 instructions against ~45 for ocml's sincosf.
+__device__ __forceinline__ void fast_sincosf(float phase, float& s, float& c) {
+  double t = (double)phase * 0.15915494309189533577;  // 1 / (2 pi)
+  t -= rint(t);
+  const float r = (float)t;
+  s = __builtin_amdgcn_sinf(r);
+  c = __builtin_amdgcn_cosf(r);
+}
+
 }  // namespace at_hip

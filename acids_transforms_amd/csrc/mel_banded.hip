@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
           float ph = p.phase_in[r * p.ld_phase + f];
           if (p.ph_offset) ph = __fadd_rn(__fmul_rn(ph, ph_sc), ph_off);
           float sn, cs;
-          sincosf(ph, &sn, &cs);
+          fast_sincosf(ph, sn, cs);
           reinterpret_cast<float2*>(p.out)[r * p.ld_out + f] = make_float2(acc * cs, acc * sn);
         } else if (p.T > 0) {
           const long long b = r / p.T, t = r - b * p.T;

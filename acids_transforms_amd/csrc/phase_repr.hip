@@ -180,7 +180,7 @@ template <bool POLAR>
 __device__ __forceinline__ void put_phase(const IntParams& p, long long idx, float ph) {
   if constexpr (POLAR) {
     float sn, cs;
-    sincosf(ph, &sn, &cs);
+    fast_sincosf(ph, sn, cs);
     const float m = p.mag[idx];
     reinterpret_cast<float2*>(p.out)[idx] = make_float2(m * cs, m * sn);
   } else {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void polar_to_complex_kernel(const float* __re
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float s, c;
-    sincosf(phase[i], &s, &c);
+    fast_sincosf(phase[i], s, c);
     const float m = mag[i];
     out[i] = make_float2(m * c, m * s);
   }

@@ -203,7 +203,7 @@ __global__ void irfft_generic_kernel(GenInvParams p) {
         v = p.X[f * Fb + k];
       } else {
         float s, c;
-        sincosf(p.phase[f * Fb + k], &s, &c);
+        fast_sincosf(p.phase[f * Fb + k], s, c);       // as the register-core kernels: fp64 reduction + v_sin / v_cos
         float m = p.mag[f * Fb + k];
         v = make_float2(m * c, m * s);
       }
