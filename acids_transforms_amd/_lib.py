@@ -157,7 +157,14 @@ def require_device(*tensors):
     return idx
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as a void*.  torch's raw-stream accessor when it exists (0.3 us;
+    `torch.cuda.current_stream()` builds a Stream object first: 8 us of the 16 a call through ops.py costs)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
