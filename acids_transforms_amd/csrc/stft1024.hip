@@ -965,10 +965,12 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
       else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true, 0, false, 4> : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 4>;
     }
   }
-  // runs of at least 24 frames so that the extra segment loads of a run start stay < 5 % (counted as
-  // 1024 / hop - 3 >= 1 frames of overhead per run)
+  // Runs of at least 8 frames.  The planner minimises rounds x (run length + per-run overhead), counting 1024 / hop - 3
+  // >= 1 frames of overhead per run start: a full batch still gets long runs (1024 clips: 173 frames each, one round),
+  // while a handful of clips is cut into many short runs that fill the idle chip -- one clip 63 -> 29 us, eight clips
+  // 66 -> 31 us (it used to stop at 24-frame runs, i.e. seven waves per second of audio).
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
-  const long long fpr = plan_units_per_run(B, T, slots, 24, hop == 128 ? 5 : 1);
+  const long long fpr = plan_units_per_run(B, T, slots, 8, hop == 128 ? 5 : 1);
   p.frames_per_run = fpr;
   p.runs_per_clip = (T + fpr - 1) / fpr;
   const long long waves = B * p.runs_per_clip;
@@ -997,9 +999,9 @@ int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, 
     kernel = hop == 128 ? istft1024_ola_kernel<IN_GL, 1, true, 1>
            : hop == 256 ? istft1024_ola_kernel<IN_GL, 1, true, 2> : istft1024_ola_kernel<IN_GL, 1, true, 4>;
   }
-  // runs of >= 32 hop slots: a run synthesises n_fft/hop - 1 frames more than it emits slots
+  // runs of >= 8 hop slots (a run synthesises n_fft/hop - 1 frames more than it emits slots: the planner's overhead term)
   const long long slots = resident_waves(kernel, 64 * WAVES_PER_BLOCK, 0);
-  const long long spr = plan_units_per_run(B, nslots, slots, 32, 1024 / hop - 1);
+  const long long spr = plan_units_per_run(B, nslots, slots, 8, 1024 / hop - 1);
   p.slots_per_run = spr;
   p.runs_per_clip = (nslots + spr - 1) / spr;
   const long long waves = B * p.runs_per_clip;

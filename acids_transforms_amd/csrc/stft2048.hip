@@ -639,7 +639,7 @@ int launch_istft2048_ola(const float2* X, const float* mag, const float* phase, 
   // runs long enough that the R - 1 warm-up frames stay a small share, short enough to fill the chip
   long long runs = (B >= 2048) ? 1 : (2048 + B - 1) / B;
   long long per = (blocks + runs - 1) / runs;
-  const long long min_per = 24;
+  const long long min_per = 8;
   if (per < min_per) per = min_per < blocks ? min_per : blocks;
   runs = (blocks + per - 1) / per;
   p.runs_per_clip = runs;

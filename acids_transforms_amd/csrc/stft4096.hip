@@ -390,7 +390,7 @@ int launch_istft4096_ola(const float2* X, const float* mag, const float* phase, 
   const long long blocks = T - 1;                        // output hops per clip
   long long runs = (B >= 2048) ? 1 : (2048 + B - 1) / B;
   long long per = (blocks + runs - 1) / runs;
-  const long long min_per = 24;
+  const long long min_per = 8;
   if (per < min_per) per = min_per < blocks ? min_per : blocks;
   runs = (blocks + per - 1) / per;
   p.runs_per_clip = runs;
