@@ -122,6 +122,11 @@ class OverlapAdd(AudioTransform):
         x3 = x.reshape((-1,) + tuple(x.shape[-2:])).contiguous()
         out, tail = ops.oadd_invert(x3, None, self._n_fft, self._hop, self._keep, self.gain_compensation)
         full = torch.cat([out, tail / self.gain_compensation, torch.zeros(out.shape[0], self._hop, device=x.device)], -1)
+        # oadd.py:65: every frame enters as x / (overlap / 2).  The kernel sums unscaled frames; for the usual
+        # power-of-two overlaps the factor commutes with the sum and the division bit for bit (golden G19).
+        overlap = int(self._n_fft / self._hop)
+        if overlap != 2:
+            full = full / (overlap / 2)
         return full.reshape(tuple(lead) + (full.shape[-1],))
 
 

@@ -787,10 +787,84 @@ def g17():
     save("g17_streaming_sizes", **out)
 
 
+# --------------------------------------------------------------------------
+# G18: the README chain end to end (README.md:48-61): Mono() + DGT(pghi) + Magnitude(mel, unipolar, log1p) ->
+# scale_data, forward, invert.  The README's `norm="unipolar"` is not a parameter of Magnitude (spectral_repr.py:152:
+# it is `mode`), so the chain is built with mode="unipolar".  The mel bank is injected (torchaudio is absent): a
+# triangular HTK-spaced bank of 513 filters over 513 bins built right here from the textbook formula -- data, not
+# the product's bank code.  Stereo input (Mono mixes it down), two clips.
+# --------------------------------------------------------------------------
+def triangular_htk_bank(n_freqs, n_mels, sr):
+    f = torch.linspace(0, sr // 2, n_freqs, dtype=torch.float64)
+    mel = lambda hz: 2595.0 * np.log10(1.0 + hz / 700.0)
+    m_pts = torch.linspace(mel(0.0), mel(sr / 2.0), n_mels + 2, dtype=torch.float64)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - f.unsqueeze(1)
+    down = -slopes[:, :-2] / diff[:-1]
+    up = slopes[:, 2:] / diff[1:]
+    return torch.clamp(torch.minimum(down, up), min=0.0).float()
+
+
+def g18():
+    sr = 44100
+    L = 16384
+    t = torch.arange(L, dtype=torch.float64) / sr
+    g = torch.Generator().manual_seed(180)
+    clips = []
+    for c in range(2):
+        left = sum(a * torch.sin(2 * np.pi * (f0 * t + 0.5 * sw * t * t) + ph)
+                   for (a, f0, sw, ph) in [(0.4, 330.0 * (c + 1), 300.0, 0.3), (0.25, 1250.0, -900.0, 1.1), (0.1, 5200.0, 0.0, 2.0)])
+        right = sum(a * torch.sin(2 * np.pi * f0 * t + ph) * torch.exp(-3.0 * t)
+                    for (a, f0, ph) in [(0.5, 523.25, 0.0), (0.2, 2093.0, 0.7)])
+        clips.append(torch.stack([left, right]).float() + 0.01 * torch.randn(2, L, generator=g))
+    x = torch.stack(clips)                      # (2 clips, 2 channels, L)
+    bank = triangular_htk_bank(513, 513, sr)
+    taf._INJECTED_BANK = bank
+    chain = at.Mono() + at.DGT(sr=sr, n_fft=1024, hop_length=256, inversion_mode="pghi") \
+        + at.Magnitude(mel=True, mode="unipolar", contrast="log1p")
+    taf._INJECTED_BANK = None
+    chain.scale_data(x)
+    y = chain(x)
+    mono = chain[0](x)
+    spec = chain[1](mono)
+    mag_inv = chain[2].invert(y)
+    x_inv = chain.invert(y)
+    save("g18_readme_chain", x=x, bank=bank, offset=chain[2].norm.offset, scale=chain[2].norm.scale, mono=mono, spec=spec,
+         y=y, mag_inv=mag_inv, x_inv=x_inv, invertible=np.array(bool(chain.invertible)))
+
+
+# --------------------------------------------------------------------------
+# G19: OverlapAdd's state helpers driven directly (oadd.py:33-67): _forward_without_update, _invert_without_update
+# (frames scaled by 2/overlap, sum divided by the gain compensation, n*hop + n_fft samples), get_input_buffer /
+# get_output_buffer over two calls.
+# --------------------------------------------------------------------------
+def g19():
+    out = {}
+    for (n, h, nfr) in [(1024, 256, 5), (1024, 128, 9), (64, 16, 7), (512, 256, 3)]:
+        key = "%d_%d" % (n, h)
+        o = at.OverlapAdd(n, h)
+        x = sig_noise((2, (nfr - 1) * h + n), 190 + n + h)
+        fr = o._forward_without_update(x)
+        out["x_" + key] = x
+        out["frames_" + key] = fr
+        frames = sig_noise((2, 3, nfr, n), 191 + n + h)
+        out["in_" + key] = frames
+        out["inv_" + key] = o._invert_without_update(frames)
+        c0 = sig_noise((2, 4 * n), 192 + n + h)
+        c1 = sig_noise((2, 4 * n), 193 + n + h)
+        out["c0_" + key] = c0
+        out["c1_" + key] = c1
+        out["inbuf0_" + key] = o.get_input_buffer(c0)
+        out["inbuf1_" + key] = o.get_input_buffer(c1)
+        out["outbuf0_" + key] = o.get_output_buffer(o._forward_without_update(c0))
+    save("g19_oadd_helpers", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     table = {"g1": g1, "g2": g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7_g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13,
-             "g14": g14, "g15": g15, "g16": g16, "g17": g17}
+             "g14": g14, "g15": g15, "g16": g16, "g17": g17, "g18": g18, "g19": g19}
     for w in which:
         print("==", w)
         table[w]()
