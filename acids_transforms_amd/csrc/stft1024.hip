@@ -16,6 +16,8 @@
 #include "fastmath.h"
 #include <type_traits>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "band_bank.h"
 #include "fft512.h"
@@ -193,14 +195,32 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
 // SP (row-major features of a one- or two-pass bank -- the 128-mel bank of the headline step): the passes are
 // unrolled and what a lane needs for them (its filter, where its walk starts, the walk's length) is read once per
 // run instead of once per pass and frame.
-template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2, int SP = 0>
+// FQ0 / FQ1 (with SP == 2): the two passes' walk lengths in quads as compile-time constants, log1p contrast and
+// |X| (not |X|^2) fixed -- the headline configuration (128 mel filters at 44.1 kHz: 8 and 2 quads).  The generic
+// epilogue spends more instructions on run-time switches (contrast mode, power, layout, loop control: 112 scalar
+// and 137 vector instructions per frame in the listing) than on the 20 multiply-adds of the walk itself; with
+// everything fixed both passes are straight-line code, their LDS reads batched and their sums independent.
+// AL: the spectrum leaves as ONE byte stream in 512-byte aligned blocks.  (B, T, 513) complex64 is contiguous and a
+// wave writes consecutive frames, but a row is 4104 bytes: row f starts 8 f bytes past a 128-byte line, every one of its
+// eight 512-byte stores straddles five lines and the Nyquist bin is a ninth, one-lane store.  With AL the output
+// COLUMNS of the FFT are rotated over the lanes by rot = (f 513) mod 64 (free: the last exchange reads through the
+// rotated index, fft512's out_lane), so that the lane number IS the position inside an aligned block of 64 bins: lanes
+// >= rot hold block j of the frame in register j, lanes < rot hold block j + 1 in register j, block 8 (the tail of
+// register 7, then the Nyquist bin on lane rot) is carried into the next frame's block 0.  Eight full, aligned 512-byte
+// stores per frame (a ninth every 64 frames), two selects per store, no masked store in the steady state.
+// NT: those stores non-temporal.  tools/ubench/stream_pattern2.hip prices the pattern: rows 4.7 TB/s, aligned blocks
+// 4.95, aligned + nt 5.0-5.3 (profiles/r03a_*).
+template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2, int SP = 0,
+          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false>
 __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
   constexpr int H = 128 * HS;
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
   __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
   extern __shared__ float4 band_lds[];   // MEL != 0: the bank's weight table, sized by the launcher
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // wave-uniform by construction; said explicitly, or everything derived from it (clip, run bounds, the frame
+  // counter of the main loop, the column rotation) lives in vector registers and the loop control runs on the VALU
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + FWD_WAVES * kFftLdsFloat2PerWave;
   // workgroup-shared constants: (twiddle table,) analysis window, band weights
@@ -277,6 +297,20 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
     ph_off = *p.ph_offset;
     ph_sc = *p.ph_scale;
   }
+  int rot = 0;                 // AL: column rotation of the current frame
+  float2* sp = nullptr;        //     this lane's slot in the current frame's block 0
+  v2f carry = {0.f, 0.f};      //     block 8 of the previous frame (lanes < rot: bins 448 + .., lane rot - 1: Nyquist)
+  bool head = true;            //     the run's first block belongs partly to the run before
+  if constexpr (AL) {
+    static_assert(MEL != 2 && !WRITE_PHASE && !POLAR && TWLDS, "aligned stream stores: spectrum out, LDS twiddles");
+    const long long e0 = (b * p.T + t0) * F;
+    rot = (int)(e0 & 63);
+    sp = p.out + (e0 - rot) + lane;
+  }
+  auto put = [&](float2* dst, v2f val) {
+    if (NT) __builtin_nontemporal_store(val, reinterpret_cast<v2f*>(dst));
+    else *reinterpret_cast<v2f*>(dst) = val;
+  };
   long long t_cur = t0;
   float cm[CMBUF ? CMBUF : 1][8];   // features of frames t_cur-7 .. t_cur (sliding), one row per pass
 #pragma unroll
@@ -307,7 +341,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
     float2 v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const float2 w = win[lane + 64 * m];
+      const v2f w = lds_read_single(reinterpret_cast<const v2f*>(win) + lane + 64 * m);
       v[m] = make_float2(raw[m].x * w.x, raw[m].y * w.y);
     }
 #pragma unroll
@@ -315,11 +349,16 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
 #pragma unroll
     for (int k = 0; k < HS; ++k) raw[8 - HS + k] = fresh[k];
     float2 nyq;
+    const int col = AL ? ((lane - rot) & 63) : lane;      // this lane ends up with bins col + 64 m
     {
       v2f z[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) z[m] = to_v(v[m]);
-      if (TWLDS) {
+      if constexpr (AL) {
+        fft512<false>(z, tw_lds, lds, lane, col);
+        const LdsTwiddles<false> tw_col = {tab, col};
+        rfft_merge_rot(z, tw_col, lane, rot, col, nyq);
+      } else if (TWLDS) {
         fft512<false>(z, tw_lds, lds, lane);
         rfft_merge(z, tw_lds, lane, nyq);
       } else {
@@ -328,8 +367,29 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
       }
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = to_f2(z[m]);
+      if constexpr (AL) {
+        const bool lo = lane < rot;
+        const v2f s0 = lo ? carry : z[0];
+        if (head) {
+          if (!lo) put(sp, s0);
+          head = false;
+        } else {
+          put(sp, s0);
+        }
+#pragma unroll
+        for (int j = 1; j < 8; ++j) put(sp + 64 * j, lo ? z[j - 1] : z[j]);
+        carry = lo ? z[7] : (v2f){nyq.x, 0.f};
+        if (rot == 63) {       // the frame ends exactly on a block boundary
+          put(sp + 512, carry);
+          sp += 576;
+          rot = 0;
+        } else {
+          sp += 512;
+          ++rot;
+        }
+      }
     }
-    if (MEL != 2) {
+    if (MEL != 2 && !AL) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) row[lane + 64 * m] = v[m];
     }
@@ -352,7 +412,52 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
       }
       prow += phase_ld;
     }
-    if (MEL != 0) {
+    if constexpr (MEL != 0 && FQ0 > 0) {
+      static_assert(SP == 2 && !CMBUF && !POLAR, "fixed-length epilogue: two passes, row-major features");
+      float* absrow = reinterpret_cast<float*>(lds);
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        absrow[col + 64 * m] = __builtin_amdgcn_sqrtf(fmaf(v[m].x, v[m].x, v[m].y * v[m].y));
+      // bin 512.  Entries 513 .. 639 are whatever the FFT left in the slab: a walk that runs past its band
+      // multiplies them by zero weights (finite leftovers: the frame's own intermediate values; a frame
+      // that holds inf / NaN yields NaN features either way)
+      if (col == 0) absrow[512] = fabsf(nyq.x);
+      wave_lds_sync();
+      const float4* a0 = reinterpret_cast<const float4*>(absrow + sp_start[0]);
+      const float4* a1 = reinterpret_cast<const float4*>(absrow + sp_start[1]);
+      const float4* w0 = reinterpret_cast<const float4*>(wlds) + lane;
+      const float4* w1 = w0 + FQ0 * 64;
+      v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < FQ1; ++j) {
+        const float4 av = a1[j], wv = w1[j * 64];
+        s1 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, s1);
+        s1 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, s1);
+      }
+      // the long pass on two independent sums (even / odd quads): half the dependent-latency chain
+#pragma unroll
+      for (int j = 0; j < FQ0; ++j) {
+        const float4 av = a0[j], wv = w0[j * 64];
+        if (j & 1) {
+          s2 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, s2);
+          s2 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, s2);
+        } else {
+          s0 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, s0);
+          s0 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, s0);
+        }
+      }
+      s0 += s2;
+      float f0v = __builtin_amdgcn_logf(1.0f + (s0.x + s0.y)) * 0.69314718055994530942f;
+      float f1v = __builtin_amdgcn_logf(1.0f + (s1.x + s1.y)) * 0.69314718055994530942f;
+      f0v = (f0v - mel_off) * mel_inv;      // no Normalize: offset 0, reciprocal 1 -- the identity, bit for bit
+      f1v = (f1v - mel_off) * mel_inv;
+      if (sp_f[0] >= 0) frow[sp_f[0]] = f0v;
+      if (sp_f[1] >= 0) frow[sp_f[1]] = f1v;
+      wave_lds_sync();
+      frow += feat_ld;
+      ++t_cur;
+    } else if (MEL != 0) {
       // |X| (or |X|^2) of this frame into the wave's LDS slab (free again after the FFT), then every lane
       // gathers the bands of its filters: sum_k |X[k]| w[k][n] over the band only (the rest of the column is 0)
       float* absrow = reinterpret_cast<float*>(lds);
@@ -360,10 +465,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const float s2 = fmaf(v[m].x, v[m].x, v[m].y * v[m].y);
-        absrow[lane + 64 * m] = p.power2 ? s2 : __builtin_amdgcn_sqrtf(s2);
+        absrow[col + 64 * m] = p.power2 ? s2 : __builtin_amdgcn_sqrtf(s2);
       }
       // bin 512, then zeros: a walk may run past its band (zero weights there), up to entry 639
-      absrow[512 + lane] = (lane == 0) ? (p.power2 ? nyq.x * nyq.x : fabsf(nyq.x)) : 0.0f;
+      absrow[512 + col] = (col == 0) ? (p.power2 ? nyq.x * nyq.x : fabsf(nyq.x)) : 0.0f;
       absrow[576 + lane] = 0.0f;
       wave_lds_sync();
       const float4* w = reinterpret_cast<const float4*>(wlds) + lane;
@@ -444,7 +549,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
       ++t_cur;
     }
     nyq_pending = nyq;
-    nyq_dst = (MEL != 2) ? row + 512 : nullptr;
+    nyq_dst = (MEL != 2 && !AL) ? row + 512 : nullptr;
     row += F;
   };
 
@@ -482,6 +587,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stf
     frame_body(fresh);
   }
   flush_nyquist();
+  if constexpr (AL) {
+    if (lane < rot) put(sp, carry);      // the run's last block: the next run (or clip) owns the rest of it
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -638,7 +746,7 @@ __device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const 
   fft512<true>(z, tw, lds, lane);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    const v2f w = reinterpret_cast<const v2f*>(win)[lane + 64 * m];   // window / 1024, workgroup-shared LDS copy
+    const v2f w = lds_read_single(reinterpret_cast<const v2f*>(win) + lane + 64 * m);   // window / 1024, workgroup-shared LDS copy
     v[m] = to_f2(z[m] * w);
   }
 }
@@ -659,7 +767,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS
   constexpr int kFull = (1 << R) - 1;
   __shared__ float2 lds_all[WAVES_PER_BLOCK * kFftLdsFloat2PerWave + 512 + (TWLDS ? kTwiddleCount : 0)];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // wave-uniform by construction; said explicitly, or everything derived from it (clip, run bounds, the frame
+  // counter of the main loop, the column rotation) lives in vector registers and the loop control runs on the VALU
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* win = lds_all + WAVES_PER_BLOCK * kFftLdsFloat2PerWave;
   float2* twtab = win + 512;
@@ -957,6 +1067,12 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
       else
         kernel = out ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2> : stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 2>;
     }
+    // ... and with the walk lengths of the headline bank (128 mel filters at 44.1 kHz: 8 + 2 quads), log1p and |X|:
+    // the fixed-length epilogue
+    if (hop == 256 && !polar && !phase && !feat_channel_major && bank->n_passes == 2 && contrast == 1 && !power2 &&
+        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && !getenv("ACIDS_GENERIC_EPILOGUE"))
+      kernel = out ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>
+                   : stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 2, 8, 2>;
     if (hop == 128) {
       if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 1>;
       else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true, 0, false, 1> : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 1>;
@@ -969,10 +1085,29 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   // >= 1 frames of overhead per run start: a full batch still gets long runs (1024 clips: 173 frames each, one round),
   // while a handful of clips is cut into many short runs that fill the idle chip -- one clip 63 -> 29 us, eight clips
   // 66 -> 31 us (it used to stop at 24-frame runs, i.e. seven waves per second of audio).
+  // Aligned stream stores (template flags AL / NT) for the two headline forms at the default hop: the plain forward and
+  // the fixed-length fused epilogue.  ACIDS_FWD_STORES = rows | aligned | aligned_nt picks the form for A/B runs.
+  {
+    static const int store_mode = [] {
+      const char* e = getenv("ACIDS_FWD_STORES");
+      if (!e) return 2;
+      return !strcmp(e, "rows") ? 0 : !strcmp(e, "aligned") ? 1 : 2;
+    }();
+    const bool al_ok = store_mode != 0 && hop == 256 && out && !phase && !polar && (((uintptr_t)out) & 511) == 0;
+    if (al_ok && !bank) {
+      NW = 8;
+      kernel = store_mode == 1 ? stft1024_h256_fwd_kernel<false, 0, 8, true, 0, false, 2, 0, 0, 0, true, false>
+                               : stft1024_h256_fwd_kernel<false, 0, 8, true, 0, false, 2, 0, 0, 0, true, true>;
+    } else if (al_ok && kernel == (void (*)(FwdRunParams))stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>) {
+      kernel = store_mode == 1 ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, false>
+                               : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, true>;
+    }
+  }
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
   const long long fpr = plan_units_per_run(B, T, slots, 8, hop == 128 ? 5 : 1);
   p.frames_per_run = fpr;
-  p.runs_per_clip = (T + fpr - 1) / fpr;
+  if (const char* e = getenv("ACIDS_FWD_FPR")) p.frames_per_run = atoll(e) > 0 ? atoll(e) : fpr;   // dev: run length A/B
+  p.runs_per_clip = (T + p.frames_per_run - 1) / p.frames_per_run;
   const long long waves = B * p.runs_per_clip;
   hipLaunchKernelGGL(kernel, dim3((unsigned)((waves + NW - 1) / NW)), dim3(64 * NW), dyn_lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -34,26 +34,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-N_FFT, HOP, SR = 1024, 256, 44100
-CLIP_LEN = 4 * SR                     # 176400 samples
-T_FRAMES = 1 + CLIP_LEN // HOP        # 690
-F_BINS = N_FFT // 2 + 1               # 513
-N_MELS = 128
-N_MFCC = 40
-HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s, ~6.3 achievable)
-MFMA_F32_PEAK_TFLOPS = 157.3          # fp32-input MFMA spec
-MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA spec
-# algorithmic bytes per frame (SURVEY.md 8d)
-BYTES_STFT_FWD = HOP * 4 + F_BINS * 8            # 5128
-BYTES_ISTFT = F_BINS * 8 + HOP * 4               # 5128
-BYTES_MEL = F_BINS * 8 + N_MELS * 4              # 4616 (unfused: reads the complex spectrum)
-BYTES_FUSED_FEATURES_ONLY = HOP * 4 + N_MELS * 4  # 1536 (spectrum never stored)
-FLOPS_MEL = 2 * F_BINS * N_MELS                  # 131328 dense
-
-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +45,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="STFT and Magnitude as two kernels")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
+    ap.add_argument("--settle-steps", type=int, default=40,
+                    help="untimed steps run BEFORE the --warmup steps so that the timed region sees the chip's sustained "
+                         "clocks (a fresh process runs its first two steps at boost clock, is then clamped ~35 %% below by "
+                         "the power controller and recovers over ~25 steps: tools/ramp_probe.py); 0 = none")
     ap.add_argument("--pghi-clips", type=int, default=1024, help="clips for the DGT+PGHI round-trip side measurement")
     ap.add_argument("--streams", type=int, default=256, help="concurrent streams for the RealtimeDGT side measurement")
     ap.add_argument("--stream-steps", type=int, default=1000, help="steps per cell of the streaming matrix")
@@ -82,10 +66,42 @@ def _free_port():
     return port
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process could open, counted WITHOUT any HIP / torch call: KFD topology nodes that have SIMDs and whose
+    render node is accessible, cut down by ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES the way the runtime applies them (a
+    list of indices or UUIDs; the list ends at the first negative entry).  An over-count is harmless: a rank whose device
+    does not exist fails on its own (`no ROCm device` / `LOCAL_RANK ... not visible`, exit 3) and the parent relays it."""
+    import glob
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            kv = dict(line.split(None, 1) for line in open(prop).read().splitlines() if " " in line)
+        except OSError:
+            continue
+        if int(kv.get("simd_count", "0")) <= 0:
+            continue                                           # a CPU node
+        minor = int(kv.get("drm_render_minor", "-1"))
+        if minor >= 0 and not os.access("/dev/dri/renderD%d" % minor, os.R_OK | os.W_OK):
+            continue                                           # not handed to this container
+        n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is None:
+            continue
+        listed = 0
+        for item in val.split(","):
+            item = item.strip()
+            if not item or item.startswith("-"):
+                break
+            listed += 1
+        n = min(n, listed)
+    return n
+
+
 def launch_ranks(args) -> int:
     n = args.gpus
     rehearsal = os.environ.get("ACIDS_BENCH_REHEARSAL") == "1"
-    ndev = torch.cuda.device_count()          # counting devices does not initialise HIP
+    ndev = visible_gpu_count()                # sysfs only: the parent neither imports torch nor touches HIP
     if not rehearsal and ndev < n:
         print(json.dumps({"error": "--gpus %d asked for, %d ROCm device(s) visible: refusing to report a smaller "
                                    "job under that name" % (n, ndev), "n_gpus_visible": ndev}))
@@ -115,6 +131,36 @@ def launch_ranks(args) -> int:
         except subprocess.TimeoutExpired:
             p.kill()
     return rc if rc >= 0 else 1
+
+
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    # The rank launcher runs HERE, before torch is imported: a parent that starts N children must be a process that
+    # has provably never initialised the GPU (torch.cuda.device_count() falls back to hipGetDeviceCount() when amdsmi
+    # is unavailable, and a process that has made a HIP call must not start further GPU processes on this pool).
+    _args = parse()
+    if _args.gpus > 1:
+        sys.exit(launch_ranks(_args))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+N_FFT, HOP, SR = 1024, 256, 44100
+CLIP_LEN = 4 * SR                     # 176400 samples
+T_FRAMES = 1 + CLIP_LEN // HOP        # 690
+F_BINS = N_FFT // 2 + 1               # 513
+N_MELS = 128
+N_MFCC = 40
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s, ~6.3 achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3          # fp32-input MFMA spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA spec
+# algorithmic bytes per frame (SURVEY.md 8d)
+BYTES_STFT_FWD = HOP * 4 + F_BINS * 8            # 5128
+BYTES_ISTFT = F_BINS * 8 + HOP * 4               # 5128
+BYTES_MEL = F_BINS * 8 + N_MELS * 4              # 4616 (unfused: reads the complex spectrum)
+BYTES_FUSED_FEATURES_ONLY = HOP * 4 + N_MELS * 4  # 1536 (spectrum never stored)
+FLOPS_MEL = 2 * F_BINS * N_MELS                  # 131328 dense
 
 
 # ----------------------------------------------------------------------------------------------
@@ -214,7 +260,7 @@ def cpu_baseline_pghi(mags, thread_counts):
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args))          # parent: no GPU call before or after this point
+        sys.exit(launch_ranks(args))          # (imported and called as a function; the script path launched above)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -229,6 +275,10 @@ def main():
     rehearsal = os.environ.get("ACIDS_BENCH_REHEARSAL") == "1"   # dev only: N ranks share cuda:0 over gloo
     if rehearsal:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        print(json.dumps({"error": "rank %d: LOCAL_RANK %d but only %d ROCm device(s) visible: refusing to run a smaller "
+                                   "job under the name --gpus %d" % (rank, local_rank, torch.cuda.device_count(), args.gpus)}))
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
@@ -406,6 +456,10 @@ def main():
             dist.destroy_process_group()
         return
 
+    # settle: the power controller's transient of a fresh process is over before the W warm-up steps start
+    # (reported as `settle_steps`; the W warm-up steps and the K timed steps follow as the contract says)
+    for _ in range(max(0, args.settle_steps)):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -427,6 +481,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * frames_per_step * args.steps / elapsed
     avg = {k: sum(v) / len(v) for k, v in ktimes.items()}
+    step_ms_events = [round(a + b + c, 4) for a, b, c in zip(ktimes["stft_fwd"], ktimes["mel"], ktimes["istft"])]
 
     extras = {}
 
@@ -723,6 +778,10 @@ def main():
         "world_size_observed": dist.get_world_size() if use_dist else 1, "backend": backend,
         "roofline": roof,
         "kernels": kernels,
+        "settle_steps": max(0, args.settle_steps),
+        "timed_step_ms": {"first": step_ms_events[0], "last": step_ms_events[-1], "min": min(step_ms_events),
+                          "max": max(step_ms_events),
+                          "note": "per-step kernel time (HIP events) inside the timed region: flat = steady state"},
     }
     result.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -749,10 +808,17 @@ def main():
                     for t in cpu}
             except Exception:
                 pass
+    failed = sorted(k for k in result if k.endswith("_error"))
     if rank == 0:
         print(json.dumps(result))
+        sys.stdout.flush()
     if use_dist:
         dist.destroy_process_group()
+    if failed:
+        # the line above is complete and valid, but a side measurement raised: say so with the exit status
+        # (the driver's record lists key names only; a silent `*_error` string would pass unnoticed)
+        sys.stderr.write("bench.py: side measurement(s) failed: %s\n" % ", ".join(failed))
+        sys.exit(4)
 
 
 def pmc_traffic(key):

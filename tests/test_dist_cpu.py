@@ -121,6 +121,42 @@ def test_bench_launcher_never_reports_a_smaller_job():
     assert r.returncode != 0 and r.stdout.count("no ROCm device") == 2
 
 
+def test_bench_launcher_parent_never_imports_torch(tmp_path):
+    """The parent of `bench.py --gpus N` starts its ranks BEFORE torch is imported and counts devices from sysfs:
+    with a `torch` on the path that raises on import (so neither torch.cuda nor hipGetDeviceCount can be reached), the
+    parent still gets as far as its own verdict (here: too few devices -> the JSON error and exit status 3); the same
+    poisoned torch makes a plain N = 1 run die at once, which shows that the trap is armed."""
+    import json
+    import subprocess
+    (tmp_path / "torch").mkdir()
+    (tmp_path / "torch" / "__init__.py").write_text("raise RuntimeError('torch imported in the launcher parent')\n")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = ""            # no devices for this test, whatever the box has
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert "torch imported in the launcher parent" not in r.stderr, r.stderr
+    assert r.returncode == 3 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus_visible"] == 0
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True,
+                        text=True, timeout=120)
+    assert r1.returncode != 0 and "torch imported in the launcher parent" in r1.stderr
+
+
+def test_visible_gpu_count_follows_the_runtime_masks(monkeypatch):
+    import bench
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    total = bench.visible_gpu_count()
+    assert total >= 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,-1,2")
+    assert bench.visible_gpu_count() == min(total, 2)          # the list ends at the first negative entry
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
+    assert bench.visible_gpu_count() == min(total, 1)
+
+
 def test_shard_bounds_cover_everything():
     from acids_transforms_amd.dist import shard_bounds
     for n in [0, 1, 7, 8, 1024, 8191]:

@@ -14,7 +14,13 @@ T = 1 + L // 256
 frames = B * T
 
 
-def timeit(fn, n=10, warm=3):
+N_ITER = int(os.environ.get("PERF_N", "10"))
+N_WARM = int(os.environ.get("PERF_WARM", "3"))
+
+
+def timeit(fn, n=None, warm=None):
+    n = N_ITER if n is None else n          # a fresh process needs ~15 launches to reach steady clocks: PERF_WARM=20 PERF_N=40
+    warm = N_WARM if warm is None else warm
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -49,11 +55,16 @@ if "melbf16" in which:
 if "mel513" in which:
     mg = A.Magnitude(mode=None).to(dev)
     report("mel513", timeit(lambda: mg(X), n=5), 4104 + 2052, 2 * 513 * 513)
-if "fused" in which or "fused2" in which:
+if "fused" in which or "fused2" in which or "fusedfeat" in which:
     mgf = A.Magnitude(n_mels=128, mode="unipolar", contrast="log1p").to(dev)
     mgf.scale_data(X[:8])
     if "fused" in which:
         report("fwd+mel fused", timeit(lambda: mgf.forward_fused(m, x, return_spectrum=True)), 5640)
+    if "fusedfeat" in which:     # the literal configs[1] forward: features only, row-major, spectrum never stored
+        from acids_transforms_amd import ops
+        off, sc = mgf._affine()
+        report("fwd+mel feat-only", timeit(lambda: ops.stft_mel_forward(x, m.window[:1024], mgf._banded(), "log1p", off, sc,
+                                                                         mgf._eps, want_spectrum=False)), 1536)
     if "fused2" in which:
         mf = A.MFCC().to(dev)   # features only: the spectrum never reaches HBM
         report("fwd+mel (no X)", timeit(lambda: mf(x)), 1024 + 512)
