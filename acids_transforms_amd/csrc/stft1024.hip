@@ -17,6 +17,7 @@
 #include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "band_bank.h"
@@ -212,7 +213,7 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
 // 4.95, aligned + nt 5.0-5.3 (profiles/r03a_*).
 template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2, int SP = 0,
           int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false>
-__global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
+__global__ __launch_bounds__(64 * FWD_WAVES, FWD_WAVES == 10 ? 5 : (TWLDS && !CMBUF) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
   constexpr int H = 128 * HS;
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
   __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
@@ -1101,6 +1102,10 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     } else if (al_ok && kernel == (void (*)(FwdRunParams))stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>) {
       kernel = store_mode == 1 ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, false>
                                : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, true>;
+      if (getenv("ACIDS_FWD_W10")) {
+        NW = 10;
+        kernel = stft1024_h256_fwd_kernel<false, 1, 10, true, 0, false, 2, 2, 8, 2, true, true>;
+      }
     }
   }
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
@@ -1109,6 +1114,12 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   if (const char* e = getenv("ACIDS_FWD_FPR")) p.frames_per_run = atoll(e) > 0 ? atoll(e) : fpr;   // dev: run length A/B
   p.runs_per_clip = (T + p.frames_per_run - 1) / p.frames_per_run;
   const long long waves = B * p.runs_per_clip;
+  if (getenv("ACIDS_DEBUG_PLAN")) {
+    hipFuncAttributes fa = {};
+    (void)hipFuncGetAttributes(&fa, (const void*)kernel);
+    fprintf(stderr, "[plan fwd] NW %d slots %lld (regs %d, static lds %zu, dyn %zu) frames/run %lld runs/clip %lld waves %lld\n", NW,
+            slots, fa.numRegs, fa.sharedSizeBytes, dyn_lds, p.frames_per_run, p.runs_per_clip, waves);
+  }
   hipLaunchKernelGGL(kernel, dim3((unsigned)((waves + NW - 1) / NW)), dim3(64 * NW), dyn_lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -8,7 +8,8 @@ i=0
 while read -r GROUP; do
   [ -z "$GROUP" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $GROUP --output-format csv -d $OUT/p$i -o pmc -- python3 $REPO/tools/perf_all.py $MODES > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed: $GROUP"
+  echo "pass $i: $GROUP"
+  timeout -k 5 150 rocprofv3 --pmc $GROUP --output-format csv -d $OUT/p$i -o pmc -- python3 $REPO/tools/perf_all.py $MODES > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed: $GROUP"
 done <<'GROUPS'
 GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
@@ -16,8 +17,10 @@ SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_W
 TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_EA0_WRREQ_STALL TCC_TOO_MANY_EA_WRREQS_STALL
 TCC_EA0_WRREQ_DRAM_CREDIT_STALL TCC_TAG_STALL TCC_BUSY TCC_EA0_RDREQ
 TCC_REQ TCC_WRITE TCC_HIT TCC_MISS
-TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TA_FLAT_WRITE_WAVEFRONTS
-TCP_PENDING_STALL_CYCLES TCP_TCC_WRITE_REQ TCP_TCC_WRITE_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCP_TA_DATA_STALL_CYCLES
+TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES
+TA_DATA_STALLED_BY_TC_CYCLES TA_FLAT_WRITE_WAVEFRONTS
+TCP_PENDING_STALL_CYCLES TCP_TCC_WRITE_REQ
+TCP_TCC_WRITE_REQ_LATENCY TCP_TCP_TA_DATA_STALL_CYCLES
 GROUPS
 cd $REPO
 python3 - "$OUT" <<'PY'

@@ -15,7 +15,7 @@ typedef float vf2 __attribute__((ext_vector_type(2)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 template <int LD, int ST, int NT>
-__global__ __launch_bounds__(256) void k(const float* __restrict__ x, const float2* __restrict__ spec_in,
+__global__ __launch_bounds__(512) void k(const float* __restrict__ x, const float2* __restrict__ spec_in,
                                          float2* __restrict__ out, float* __restrict__ audio, long long total,
                                          long long G, long long nwaves, float* sink) {
   const int lane = threadIdx.x & 63;
@@ -107,7 +107,47 @@ static void run(const char* name, long long G, int wpb, int bpc) {
   fflush(stdout);
 }
 
-int main() {
+__global__ __launch_bounds__(256) void fill_k(vf4* __restrict__ out, long long n16, int nt) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const vf4 v = {1.f, 2.f, 3.f, 4.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    if (nt) __builtin_nontemporal_store(v, out + i); else out[i] = v;
+  }
+}
+static void run_fill(int bpc, int nt) {
+  const long long n16 = B * T * 513 * 8 / 16;
+  hipEvent_t ev_s, ev_e;
+  CHECK(hipEventCreate(&ev_s)); CHECK(hipEventCreate(&ev_e));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fill_k, dim3(256 * bpc), dim3(256), 0, 0, (vf4*)spec, n16, nt);
+  CHECK(hipEventRecord(ev_s, 0));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(fill_k, dim3(256 * bpc), dim3(256), 0, 0, (vf4*)spec, n16, nt);
+  CHECK(hipEventRecord(ev_e, 0)); CHECK(hipEventSynchronize(ev_e));
+  float ms; CHECK(hipEventElapsedTime(&ms, ev_s, ev_e)); ms /= 10;
+  printf("grid-stride fill 16 B/lane%s, %d blocks/CU: %.3f ms  %.2f TB/s\n", nt ? " nt" : "", bpc, ms, n16 * 16.0 / ms / 1e9);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) {     // second sweep: very short chunks (a compact write front) and the plain fill ceiling
+    CHECK(hipMalloc(&x, B * L * 4)); CHECK(hipMalloc(&spec, B * T * 513 * 8 + 4096)); CHECK(hipMalloc(&spec2, B * T * 513 * 8 + 4096));
+    CHECK(hipMalloc(&audio, B * L * 4)); CHECK(hipMalloc(&sink, 64));
+    CHECK(hipMemset(x, 0, B * L * 4)); CHECK(hipMemset(spec2, 0, B * T * 513 * 8 + 4096));
+    for (int bpc : {2, 4, 8}) { run_fill(bpc, 0); run_fill(bpc, 1); }
+    for (int occ : {16, 24, 32}) {
+      const int wpb = 8, bpc = occ / 8;
+      printf("---- %d waves per CU\n", occ);
+      for (long long G : {1LL, 2LL, 4LL, 8LL, 32LL}) {
+        run<0, 2, 0>("write flat 512-B aligned (8 B)", G, wpb, bpc);
+        run<0, 2, 1>("write flat 512-B aligned nt", G, wpb, bpc);
+        run<0, 3, 1>("write flat 1-KB aligned nt", G, wpb, bpc);
+        run<1, 2, 0>("fwd: audio -> flat 512-B aligned", G, wpb, bpc);
+        run<1, 2, 1>("fwd: audio -> flat 512-B aligned nt", G, wpb, bpc);
+        run<1, 3, 1>("fwd: audio -> flat 1-KB aligned nt", G, wpb, bpc);
+        run<2, 4, 0>("inv: rows -> audio", G, wpb, bpc);
+        run<2, 4, 1>("inv: rows -> audio nt", G, wpb, bpc);
+      }
+    }
+    return 0;
+  }
   CHECK(hipMalloc(&x, B * L * 4)); CHECK(hipMalloc(&spec, B * T * 513 * 8 + 4096)); CHECK(hipMalloc(&spec2, B * T * 513 * 8 + 4096));
   CHECK(hipMalloc(&audio, B * L * 4)); CHECK(hipMalloc(&sink, 64));
   CHECK(hipMemset(x, 0, B * L * 4)); CHECK(hipMemset(spec2, 0, B * T * 513 * 8 + 4096));
