@@ -569,7 +569,9 @@ __global__ __launch_bounds__(512) void pghi_hgi_offline_coop_kernel(HgiParams p)
   // workgroup's waves are spread evenly over the CU's four SIMDs, whereas 64-thread workgroups are placed by the
   // dispatcher as it sees fit -- and a SIMD that is handed one clip more than its neighbours finishes them all later:
   // the kernel's tail (4096 clips: 2.00 s as 4096 single-wave workgroups, 1.53 s as 512 eight-wave ones).
-  const int wave = threadIdx.x >> 6;
+  // The wave number is uniform by construction; said explicitly (readfirstlane), the clip's base pointers, the heap
+  // descriptor and the segment table live in scalar registers and every cell / heap address is base + 32-bit offset.
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long b = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
   if (b >= p.B) return;
   const int lane = threadIdx.x & 63;

@@ -103,7 +103,10 @@ class StreamingDGTSession:
         ops.oadd_push_(self.buf, self.x_in, self.keep)                   # history + chunk, in place
         X = ops.stft_forward(self.buf, self.dgt.window[:n_fft], n_fft, h, center=False, T=n,
                              clip_stride=self.buf.stride(0), L=(n - 1) * h + n_fft, B=self.S)
-        mag = ops.mag_pointwise(X, out=self.mag_out)                     # |X|
+        # |X| of the analysis.  `mag_out` holds exactly this -- the magnitudes BEFORE `magnitude_fn` (until round 2 it
+        # was a copy taken after it); a magnitude_fn that edits its argument in place edits this buffer too.  What
+        # was resynthesised is `mag_out` itself when there is no magnitude_fn, otherwise that function's result.
+        mag = ops.mag_pointwise(X, out=self.mag_out)
         if self.mel is not None:
             m = self.mel
             if m.bank_dtype == "bf16":

@@ -249,7 +249,7 @@ class STFT(AudioTransform):
             env = torch.zeros(expected, dtype=torch.float64)
             idx = (torch.arange(T).unsqueeze(1) * h + torch.arange(n).unsqueeze(0)).reshape(-1)
             env.index_add_(0, idx, w2.repeat(T))
-            core = env[n // 2:n // 2 + h * (T - 1)]
+            core = env[n // 2:n // 2 + h * (T - 1) + (n & 1)]      # torch.istft keeps one more sample when n_fft is odd
             cache[key] = float(core.abs().min()) if core.numel() else 1.0
         if cache[key] < 1e-11:
             raise RuntimeError("istft(n_fft=%d, hop_length=%d): window overlap add min: %g -- the window envelope "

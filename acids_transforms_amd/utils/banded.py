@@ -171,7 +171,9 @@ class BandedBank:
                            and weights.size <= FUSED_TABLE_FLOATS
                            and 4 * (8 * row512 + weights.size) + 8 * 64 * self.n_passes <= 48 * 1024)
         self.eligible = True
-        self.fusable = (self.n_passes <= FUSED_MAX_PASSES and self.lmax <= FUSED_MAX_BAND
+        # (K == 513: the fused n_fft = 1024 epilogue walks a 513-bin row; a bank built for another n_fft would be walked
+        #  against the wrong spectrum without any shape check on the way -- ADVICE r2)
+        self.fusable = (K == 513 and self.n_passes <= FUSED_MAX_PASSES and self.lmax <= FUSED_MAX_BAND
                         and weights.size <= FUSED_TABLE_FLOATS
                         and int(lane_start.max()) + int(pass_len.max()) <= FUSED_ROW_FLOATS)
         # the features-only n_fft = 2048 kernel (stft2048.hip): same walk limits, its own LDS row (sized per launch)

@@ -256,6 +256,50 @@ def cpu_baseline_pghi(mags, thread_counts):
     return out
 
 
+def cpu_baseline_northstar(samples, threads):
+    """The north-star chain on the host: Mono -> DGT -> |.| -> mel bank -> log1p -> unipolar normalise, and back
+    (de-normalise, expm1, inverse bank, PGHI, polar ISTFT with the dual window), as the oracle states it: torch CPU ops
+    with `threads` threads + the exact-order C PGHI, one clip per thread.  `samples`: {tag: (clips, 2, L) stereo audio}.
+    A bounded sample of the GPU leg's own inputs."""
+    from oracle import oracle as O
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    out = {}
+    try:
+        win = O.gauss_window(N_FFT)
+        dual = O.dual_window(win, N_FFT, HOP)
+        fwd, inv = O.magnitude_banks(O.melscale_fbanks(F_BINS, 0.0, SR / 2, F_BINS, SR))   # the reference's 513-filter bank
+        for tag, xs in samples.items():
+            n = xs.shape[0]
+            t0 = time.perf_counter()
+            mono = xs.sum(-2) / 2
+            X = O.stft_forward(mono, win, N_FFT, HOP)
+            off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
+            y = O.magnitude_forward(X, fwd, "log1p", off, sc)
+            t1 = time.perf_counter()
+            mag = O.magnitude_invert(y, inv, "log1p", off, sc)
+            phase = O.pghi_offline_batch(mag.numpy(), N_FFT, HOP, threads=threads)
+            audio = O.polar_istft(mag, torch.from_numpy(phase), dual, N_FFT, HOP)
+            t2 = time.perf_counter()
+            del audio
+            out[tag] = {"value": n * T_FRAMES / (t2 - t0), "unit": "frames/s", "cores": threads, "kind": "port",
+                        "forward_s": t1 - t0, "invert_s": t2 - t1,
+                        "sample": "%d stereo clips x 4 s, %s; oracle chain (torch CPU + exact-heap C PGHI), %d threads"
+                                  % (n, tag, threads)}
+    finally:
+        torch.set_num_threads(prev)
+    return out
+
+
+# genuine-reference composite, extrapolated from BASELINE.md section 2 (reference imported in the build container, 8
+# vCPU): forward STFT+Magnitude 124 k frames/s; Magnitude.invert taken as its forward (294 k); torch.istft 311 k;
+# DGT.invert(pghi) 12.7 frames/s on dense noise, 753 frames/s on a tonal clip (pure-Python heap, one core)
+REFERENCE_COMPOSITE = {
+    "noise": 1.0 / (1 / 124e3 + 1 / 294e3 + 1 / 12.7 + 1 / 311e3),
+    "tonal": 1.0 / (1 / 124e3 + 1 / 294e3 + 1 / 753.0 + 1 / 311e3),
+}
+
+
 # ----------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -623,11 +667,72 @@ def main():
                 pops = int((m >= thr).sum())
                 pg["%s_clips_%d" % (tag, nb)] = {"frames_per_s": nb * T_FRAMES / dt, "seconds": dt,
                                                  "heap_pops_per_s": pops / dt, "bins_above_tolerance": pops / m.numel()}
+                if nb == sizes[0]:
+                    # outside the timing: what the timed call produced, clips {0, nb/2-1, nb-1}, against the exact-order
+                    # C oracle -- pop order bit for bit (results do not depend on the batch a clip rides in, so the
+                    # order is re-recorded on those three clips alone) and the audio by SNR
+                    pg["%s_spot_check" % tag] = pghi_spot_check(dgt, m, yp, sorted({0, nb // 2 - 1 if nb > 1 else 0, nb - 1}))
                 del m, yp, xs
         pg["input"] = ("noise: |DGT(randn*0.1)|, ~100% of bins above tolerance; tonal: 8 decaying sinusoids per clip; "
                        "decaying: noise x exp(-8 t), ~10% of bins, ~300 reseeds per clip; "
                        "DGT.invert(mag, 'pghi') = gradients + heap integration + polar ISTFT")
         return pg
+
+    def pghi_spot_check(dgt, m, yp, ids):
+        from oracle import oracle as O
+        from acids_transforms_amd import ops as _ops
+        sub = m[ids].contiguous()
+        _, npops, order = _ops.pghi_offline(sub, float(dgt.gamma), N_FFT, HOP, float(dgt.tolerance), float(dgt.eps), debug=True)
+        dual = dgt.inv_window[:N_FFT].cpu()
+        worst_snr, order_ok, pops = float("inf"), True, 0
+        for j, b in enumerate(ids):
+            mb = sub[j].cpu()
+            r = O.pghi_offline(mb, N_FFT, HOP, tol=float(dgt.tolerance), want_order=True)
+            k = len(r["order"])
+            pops += k
+            got = order[j][:k].cpu().numpy()
+            order_ok = order_ok and int(npops[j]) == k and bool((got == r["order"][:, 0] * F_BINS + r["order"][:, 1]).all())
+            ref = O.polar_istft(mb.unsqueeze(0), torch.from_numpy(r["phase"]).unsqueeze(0), dual, N_FFT, HOP)[0].double()
+            err = yp[b].cpu().double() - ref
+            worst_snr = min(worst_snr, 10.0 * float(torch.log10(ref.pow(2).sum() / err.pow(2).sum().clamp_min(1e-300))))
+        return {"clips": ids, "pops_checked": pops, "pop_order_identical": order_ok, "min_audio_snr_db": round(worst_snr, 1),
+                "ok": bool(order_ok and worst_snr > 40.0),
+                "note": "vs oracle/pghi_ref.c: heap pop order bit for bit; audio of the TIMED call vs istft(mag e^{i phase_oracle})"}
+
+    def extra_northstar(collect):
+        # north_star's composite: the reference README's chain (README.md:48-61) Mono() + DGT(pghi) + Magnitude(mel,
+        # unipolar, log1p), scale_data once, then forward AND invert on B clips x 4 s of stereo audio, one timed call each
+        chain = (A.Mono() + A.DGT(sr=SR, n_fft=N_FFT, hop_length=HOP, inversion_mode="pghi")
+                 + A.Magnitude(sr=SR, mel=True, mode="unipolar", contrast="log1p")).to(dev)
+        res = {"chain": repr(chain), "clips": B}
+        for tag in ("noise", "tonal"):
+            if tag == "noise":
+                xs = torch.stack([x, x.flip(0)], 1)                                  # (B, 2, L) stereo
+            else:
+                tn = synth_tonal(B, CLIP_LEN, device=dev)
+                xs = torch.stack([tn, 0.5 * tn.roll(1, 0)], 1)
+            chain.scale_data(xs[:64])
+            y = chain(xs)
+            back = chain.invert(y)                                                   # warm-up: workspaces, caches
+            del back
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            y = chain(xs)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            back = chain.invert(y)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            res[tag] = {"frames_per_s": B * T_FRAMES / (t3 - t1), "forward_s": t2 - t1, "invert_s": t3 - t2,
+                        "out_shape": list(back.shape), "finite": bool(torch.isfinite(back).all())}
+            collect[tag] = xs[:64].cpu()
+            del xs, y, back
+        res["reference_extrapolated_frames_per_s"] = dict(REFERENCE_COMPOSITE)
+        res["vs_reference_extrapolated"] = {t: res[t]["frames_per_s"] / REFERENCE_COMPOSITE[t] for t in ("noise", "tonal")}
+        res["target"] = ">= 100x the reference CPU STFT+mel+PGHI-invert throughput (north_star)"
+        res["note"] = ("forward = mix-down + fused DGT/mel kernel; invert = banded inverse bank + PGHI (gradients, heap "
+                       "integration) + polar ISTFT + channel axis; reference figure: BASELINE.md section 2, extrapolated")
+        return res
 
     def extra_stream():
         # BASELINE configs[4]: 256 streams, RealtimeDGT fwd + bf16-MFMA mel + RTPGHI + inverse + overlap-add, one
@@ -753,6 +858,7 @@ def main():
         return {"seconds": dt, "frames_per_s": frames_per_step / dt, "iterations": 30}
 
     pghi_inputs = {}
+    northstar_inputs = {}
     if not args.no_extras:
         if rank == 0:
             guarded("hbm_probe", extra_hbm_probe)
@@ -764,6 +870,7 @@ def main():
         guarded("config4", lambda: config4_figures(max(10, args.steps // 5), 3))     # all ranks: it holds collectives
         if rank == 0 and args.pghi_clips > 0:
             guarded("pghi_invert", lambda: extra_pghi(pghi_inputs))
+            guarded("northstar_pipeline", lambda: extra_northstar(northstar_inputs))
         if rank == 0 and args.streams > 0:
             guarded("realtime_dgt_stream", extra_stream)
         barrier()
@@ -799,6 +906,12 @@ def main():
         result["cpu_baseline"] = sweep[best]
         result["cpu_baseline_1thread"] = sweep[1]
         result["cpu_baseline_sweep"] = {str(t): round(v["value"], 1) for t, v in sweep.items()}
+        if northstar_inputs and "northstar_pipeline" in result:
+            th = min(hc["affinity"], 2 * hc["usable"])
+            cpu_ns = cpu_baseline_northstar(northstar_inputs, th)
+            result["cpu_baseline_northstar"] = cpu_ns
+            result["northstar_pipeline"]["vs_host_port_all_cores"] = {
+                t: result["northstar_pipeline"][t]["frames_per_s"] / cpu_ns[t]["value"] for t in cpu_ns}
         if pghi_inputs:
             # one clip per thread: oversubscribed threads only queue, so every hardware thread we may run on is used
             result["cpu_baseline_pghi"] = cpu_baseline_pghi(pghi_inputs, [hc["usable"], 2 * hc["usable"], hc["affinity"]])

@@ -35,7 +35,9 @@ extern "C" {
 #define AT_EWORKSPACE (-4) /* workspace too small */
 #define AT_ELAUNCH (-5)    /* HIP launch / runtime error */
 
-/* 2 since round 2 (at_sinebank_realtime gained the window argument; at_mel_*bf16*, at_oadd_push added) */
+/* Returns 3.  History: 2 early in round 2 (at_sinebank_realtime gained the window argument; at_mel_*bf16*, at_oadd_push
+ * added); 3 later in round 2 (at_pghi_realtime_seeded, at_phase_*_strided / _polar, at_cartesian_*).  Round 3 changed
+ * kernels only: no signature moved. */
 int at_abi_version(void);
 const char *at_error_string(int code);
 
