@@ -8,6 +8,8 @@ import torch
 from conftest import rel_max
 from oracle import oracle as O
 
+T_ = torch.from_numpy
+
 T = torch.from_numpy
 
 
@@ -408,3 +410,43 @@ def test_rtpghi_kernel_other_sizes(golden, tag):
     ref = g[tag + "_phase"]
     tol_arr = 2e-3 + 16 * np.spacing(np.abs(ref).astype(np.float32)) + 1e-5 * np.abs(ref)
     assert np.all(np.abs(r["phase"] - ref) <= tol_arr)
+
+
+def test_readme_chain(golden):
+    """G18: Mono() + DGT(pghi) + Magnitude(mel, unipolar, log1p) (reference README.md:48-61) stage by stage and end to
+    end: the oracle's chain against the reference's own outputs."""
+    g = golden("g18_readme_chain")
+    x = T_(g["x"])
+    mono = O.mono_mix(x)
+    assert torch.equal(mono, T_(g["mono"]))
+    win = O.gauss_window(1024)
+    X = O.stft_forward(mono, win, 1024, 256)
+    assert rel_max(X.numpy(), g["spec"]) < 1e-6
+    fwd, inv = O.magnitude_banks(T_(g["bank"]))
+    off, sc = O.magnitude_scale_stats(X, "log1p", "unipolar")
+    assert abs(float(off) - float(g["offset"])) < 1e-6 and abs(float(sc) - float(g["scale"])) < 1e-6 * float(g["scale"])
+    y = O.magnitude_forward(X, fwd, "log1p", off, sc)
+    assert rel_max(y.numpy(), g["y"]) < 1e-6
+    mag = O.magnitude_invert(T_(g["y"]), inv, "log1p", off, sc)
+    assert rel_max(mag.numpy(), g["mag_inv"]) < 1e-5
+    # PGHI + polar ISTFT on the reference's own inverse-mel magnitudes: the reference's audio
+    mag_ref = T_(g["mag_inv"])
+    phase = np.stack([O.pghi_offline(mag_ref[b], 1024, 256)["phase"] for b in range(mag_ref.shape[0])])
+    audio = O.polar_istft(mag_ref, T_(phase), O.dual_window(win, 1024, 256), 1024, 256)
+    ref = g["x_inv"][:, 0]
+    err = audio.numpy().astype(np.float64) - ref
+    assert 10 * np.log10((ref.astype(np.float64) ** 2).sum() / max((err ** 2).sum(), 1e-300)) > 60.0
+
+
+@pytest.mark.parametrize("n,h", [(1024, 256), (1024, 128), (64, 16), (512, 256)])
+def test_overlap_add_helpers(golden, n, h):
+    """G19: the stateless framing / overlap-add pair and the buffer helpers (oadd.py:33-67)."""
+    g = golden("g19_oadd_helpers")
+    key = "%d_%d" % (n, h)
+    st = O.OverlapAddState(n, h)
+    assert torch.equal(O.frame(T_(g["x_" + key]), n, h), T_(g["frames_" + key]))
+    assert rel_max(st.invert_without_update(T_(g["in_" + key])).numpy(), g["inv_" + key]) < 1e-7
+    c0, c1 = T_(g["c0_" + key]), T_(g["c1_" + key])
+    st.forward(c0)
+    assert torch.equal(st.inbuf, T_(g["inbuf1_" + key]))         # what the second get_input_buffer call hands back
+    assert float(np.abs(g["inbuf0_" + key]).max()) == 0.0 and float(np.abs(g["outbuf0_" + key]).max()) == 0.0
