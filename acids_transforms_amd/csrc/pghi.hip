@@ -18,6 +18,7 @@
 #include "fastmath.h"
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/acids_hip.h"
 
@@ -563,7 +564,8 @@ __device__ __forceinline__ int coop_bubble(const HEAP& H, int n, int lane, u64 a
   return pos;
 }
 
-template <bool PROF>
+// PUSH_BATCH (opt-in, ACIDS_PGHI_PUSH=batch): round-3 experiment, measured slower -- see the comment at the pushes.
+template <bool PROF, bool PUSH_BATCH = false>
 __global__ __launch_bounds__(512) void pghi_hgi_offline_coop_kernel(HgiParams p) {
   // one wave per clip; 1, 2, 4 or 8 waves per workgroup (independent: no workgroup-level synchronisation).  A
   // workgroup's waves are spread evenly over the CU's four SIMDs, whereas 64-thread workgroups are placed by the
@@ -673,11 +675,33 @@ __global__ __launch_bounds__(512) void pghi_hgi_offline_coop_kernel(HgiParams p)
       const u64 lvmask = __ballot(lv);
       const long long t4 = PROF ? TICK() : 0;
       const u64 mine = pack_item(-s, nb);
+      // heappush x (0..4), in lane order (heapq.py:45-48).
+      // PUSH_BATCH (experiment, off by default): an entry that stays at its leaf changes nothing its successors look
+      // at (their parents lie above the old end of the heap once it holds four entries), so all candidates test their
+      // own parent in ONE round on their own lanes, the leading run of entries that stay put is stored at once, and
+      // only from the first entry that does rise onwards the pushes take the cooperative sift one after the other.
+      // Exact (PGHI suite green), but on dense spectra most pushed entries DO rise: the parent test is then paid on
+      // top of the sift -- pushes 816 -> 1115 cycles per pop, 1024 dense clips 0.695 -> 0.743 s
+      // (profiles/r03_pghi_kernels.md).
+      int first_slow = 0;
+      if (PUSH_BATCH && lvmask != 0 && hn >= 4) {
+        const int rank = __builtin_popcountll(lvmask & ((1ull << lane) - 1ull));   // lanes 0..3 matter
+        const int my_pos = hn + rank;
+        const u64 par = H.load_if((my_pos - 1) >> 1, lv, 0);
+        const bool rise = lv && (item_key(mine) < item_key(par));
+        const u64 rmask = __ballot(rise);
+        first_slow = rmask ? __builtin_ctzll(rmask) : 4;
+        const bool fast = lv && lane < first_slow;
+        if (fast) H.store(my_pos, mine);
+        const int n_fast = __builtin_popcountll(lvmask & ((1ull << first_slow) - 1ull));
+        hn += n_fast;
+        n_push += n_fast;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if ((lvmask >> q) & 1ull) {
+        if (q >= first_slow && ((lvmask >> q) & 1ull)) {
           const u64 item = readlane64(mine, q);
-          coop_siftdown(H, hn, item, lane);  // heappush (heapq.py:45-48)
+          coop_siftdown(H, hn, item, lane);
           ++hn;
           ++n_push;
         }
@@ -1632,6 +1656,8 @@ static int pghi_integrate_launch(float* spec, const float* tg, const float* fg, 
     hipLaunchKernelGGL(pghi_hgi_offline_wbit_kernel, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(64 * wpb), block_lds, s, h);
   } else {
     void (*kernel)(HgiParams) = prof ? pghi_hgi_offline_coop_kernel<true> : pghi_hgi_offline_coop_kernel<false>;
+    if (const char* e = getenv("ACIDS_PGHI_PUSH"))        // dev A/B: "batch" = the parent pre-test of the pushes (slower)
+      if (!strcmp(e, "batch")) kernel = prof ? pghi_hgi_offline_coop_kernel<true, true> : pghi_hgi_offline_coop_kernel<false, true>;
     // waves per workgroup: as many (<= 8) as keep the workgroup's heap tops within the CU's 160 KB
     int wpb = per_cu >= 8 ? 8 : per_cu >= 4 ? 4 : per_cu >= 2 ? 2 : 1;
     while (wpb > 1 && heap_lds * wpb > 160 * 1024 - 1024) wpb >>= 1;

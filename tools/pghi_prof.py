@@ -15,7 +15,7 @@ o = order[0][:20].cpu().numpy().view("int64")
 n = o[0]
 names = ["pop1(load last/root, issue nb)", "bubble rounds", "final siftdown", "neighbour update", "pushes"]
 tot = sum(o[1:6])
-print("pops", n, "pushes", o[6], "ticks/pop total %.0f (s_memtime @100MHz => %.2f us)" % (tot / n, tot / n / 100.0))
+print("pops", n, "pushes", o[6], "ticks/pop total %.0f (shader cycles; %.2f us at 2.1 GHz)" % (tot / n, tot / n / 2100.0))
 for i, nm in enumerate(names):
     print("  %-32s %7.1f ticks/pop  %4.1f%%" % (nm, o[1 + i] / n, 100.0 * o[1 + i] / tot))
 
