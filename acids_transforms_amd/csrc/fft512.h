@@ -190,6 +190,19 @@ struct LdsTwiddles {
   __device__ __forceinline__ v2f get2(int k) const { return lds_read_single(reinterpret_cast<const v2f*>(tab) + (7 + k) * 64 + lane); }
   __device__ __forceinline__ v2f getr(int m) const { return lds_read_single(reinterpret_cast<const v2f*>(tab) + (14 + m) * 64 + lane); }
 };
+// ... or both: the two pass tables (14 rows, indexed by the physical lane) in registers, the W1024 rows of the real
+// merge read from LDS through `col` -- what the kernels with rotated output columns need (the merge's twiddle follows
+// the column, which changes from frame to frame), at 14 fewer LDS reads per frame than LdsTwiddles.
+struct HybridTwiddles {
+  v2f t1[7];
+  v2f t2[7];
+  const float2* tab;
+  int col;
+  __device__ __forceinline__ v2f get1(int k) const { return t1[k]; }
+  __device__ __forceinline__ v2f get2(int k) const { return t2[k]; }
+  __device__ __forceinline__ v2f getr(int m) const { return lds_read_single(reinterpret_cast<const v2f*>(tab) + (14 + m) * 64 + col); }
+};
+
 template <bool INV>
 __device__ __forceinline__ float2 twiddle_for_lds(const float2* __restrict__ tab, int i) {
   const float2 a = tab[i];

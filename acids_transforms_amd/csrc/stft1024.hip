@@ -212,8 +212,11 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
 // NT: those stores non-temporal.  tools/ubench/stream_pattern2.hip prices the pattern: rows 4.7 TB/s, aligned blocks
 // 4.95, aligned + nt 5.0-5.3 (profiles/r03a_*).
 template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2, int SP = 0,
-          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false>
-__global__ __launch_bounds__(64 * FWD_WAVES, FWD_WAVES == 10 ? 5 : (TWLDS && !CMBUF) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
+          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false, int HYB = 0>
+__global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
+  // HYB (with TWLDS): bit 0 -- the two pass twiddle tables in registers, only the merge's W1024 rows from LDS
+  // (HybridTwiddles); bit 1 -- the analysis window in registers.  Both trade LDS reads (the busiest unit of these
+  // kernels) for VGPRs, i.e. for the fourth wave per SIMD.
   constexpr int H = 128 * HS;
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
   __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
@@ -266,7 +269,22 @@ __global__ __launch_bounds__(64 * FWD_WAVES, FWD_WAVES == 10 ? 5 : (TWLDS && !CM
   Twiddles tw_regs;
   if (!TWLDS) load_twiddles<false>(tw_regs, p.tw, lane);
   const LdsTwiddles<false> tw_lds = {tab, lane};
+  HybridTwiddles tw_hyb;
+  if constexpr (TWLDS && (HYB & 1)) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      tw_hyb.t1[k] = to_v(p.tw[k * 64 + lane]);
+      tw_hyb.t2[k] = to_v(p.tw[(7 + k) * 64 + lane]);
+    }
+    tw_hyb.tab = tab;
+    tw_hyb.col = lane;
+  }
   const float2* win = tab + kTabTw;   // win[lane + 64 m]
+  v2f win_regs[8];
+  if constexpr ((HYB & 2) != 0) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) win_regs[m] = to_v(reinterpret_cast<const float2*>(p.window)[lane + 64 * m]);
+  }
 
   const float* clip = p.x + b * p.clip_stride;
   const bool clip_aligned = ((((uintptr_t)clip) & 7) == 0);  // frame starts are multiples of 256 samples
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, FWD_WAVES == 10 ? 5 : (TWLDS && !CM
     float2 v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const v2f w = lds_read_single(reinterpret_cast<const v2f*>(win) + lane + 64 * m);
+      const v2f w = (HYB & 2) ? win_regs[m] : lds_read_single(reinterpret_cast<const v2f*>(win) + lane + 64 * m);
       v[m] = make_float2(raw[m].x * w.x, raw[m].y * w.y);
     }
 #pragma unroll
@@ -355,10 +373,17 @@ __global__ __launch_bounds__(64 * FWD_WAVES, FWD_WAVES == 10 ? 5 : (TWLDS && !CM
       v2f z[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) z[m] = to_v(v[m]);
-      if constexpr (AL) {
+      if constexpr (AL && (HYB & 1)) {
+        fft512<false>(z, tw_hyb, lds, lane, col);
+        tw_hyb.col = col;
+        rfft_merge_rot(z, tw_hyb, lane, rot, col, nyq);
+      } else if constexpr (AL) {
         fft512<false>(z, tw_lds, lds, lane, col);
         const LdsTwiddles<false> tw_col = {tab, col};
         rfft_merge_rot(z, tw_col, lane, rot, col, nyq);
+      } else if constexpr (TWLDS && (HYB & 1)) {
+        fft512<false>(z, tw_hyb, lds, lane);
+        rfft_merge(z, tw_hyb, lane, nyq);
       } else if (TWLDS) {
         fft512<false>(z, tw_lds, lds, lane);
         rfft_merge(z, tw_lds, lane, nyq);
@@ -1102,10 +1127,17 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     } else if (al_ok && kernel == (void (*)(FwdRunParams))stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>) {
       kernel = store_mode == 1 ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, false>
                                : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, true>;
-      if (getenv("ACIDS_FWD_W10")) {
-        NW = 10;
-        kernel = stft1024_h256_fwd_kernel<false, 1, 10, true, 0, false, 2, 2, 8, 2, true, true>;
-      }
+    }
+    // Features only (the spectrum never stored) is bound by the LDS and by instruction issue, not by HBM: with both
+    // pass-twiddle tables and the window in registers (HYB = 3: 30 fewer LDS reads per frame) at three waves per SIMD --
+    // three 4-wave blocks per CU -- it runs 4 % faster than with four waves that read everything from LDS (0.642 ->
+    // 0.615 ms, same box, alternating runs).  The spectrum-storing forms did not move with any HYB setting (fused 0.867
+    // / 0.866 / 0.869 ms, plain 0.756 / 0.758 / 0.779): their waves wait on store issue, and the plain one loses its
+    // fifth and sixth wave.  5 waves per SIMD (10-wave blocks, 96 registers, 2 spilled): 0.65 -> 0.69 ms.
+    if (kernel == (void (*)(FwdRunParams))stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 2, 8, 2> &&
+        !getenv("ACIDS_FWD_NOHYB")) {
+      NW = 4;
+      kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 0, false, 2, 2, 8, 2, false, false, 3>;
     }
   }
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);

@@ -23,8 +23,10 @@ def short(name):
 
 print("# rocprofv3 summary `%s`\n" % tag)
 STEPS, WARM = int(os.environ.get("PROFILE_STEPS", "20")), int(os.environ.get("PROFILE_WARMUP", "5"))
-print("Command: `python3 bench.py --steps %d --warmup %d --no-cpu-baseline --no-extras` (B=1024 clips x 4 s, 1 GPU)\n"
-      % (STEPS, WARM))
+SETTLE = int(os.environ.get("PROFILE_SETTLE", "40"))          # bench.py --settle-steps (untimed, before the warm-up steps)
+print("Command: `python3 bench.py --steps %d --warmup %d --no-cpu-baseline --no-extras` (B=1024 clips x 4 s, 1 GPU; "
+      "%d settle steps before the warm-up)\n" % (STEPS, WARM, SETTLE))
+WARM += SETTLE
 print("`timed avg` = the launches of bench.py's timed region only (the last %d of a step kernel before the side "
       "measurements): the first launches run on cold clocks and untouched pages and are what `avg` over all calls "
       "adds to it.\n" % STEPS)
