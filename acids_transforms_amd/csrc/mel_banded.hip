@@ -108,7 +108,7 @@ template <bool CPLX, int NSEG, bool EXACT, int CMW = 0>
 __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedParams p) {
   extern __shared__ float4 band_lds[];   // weight table, lane_start / lane_filter, one row per wave
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bookkeeping on the scalar unit
   const int n_thr = blockDim.x;
   float* wlds = reinterpret_cast<float*>(band_lds);
   const int table_floats = p.table_floats;

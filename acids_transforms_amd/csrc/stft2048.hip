@@ -114,7 +114,7 @@ __device__ __forceinline__ void stage_tables2k(const P2k& p, float2* tab, float2
 template <bool WRITE_PHASE>
 __global__ __launch_bounds__(64 * W2K, 3) void stft2048_fwd_kernel(P2k p) {
   __shared__ float2 lds_all[W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W2K * kFftLdsFloat2PerWave;
   const v2f* w2 = reinterpret_cast<const v2f*>(tab + kTwiddleCount) + lane;     // w2[64 m] = W2048^(lane + 64 m)
@@ -182,7 +182,7 @@ __device__ __forceinline__ void sincos_big2k(float phase, float& s, float& c) {
 template <bool POLAR>
 __global__ __launch_bounds__(64 * W2K, 3) void irfft2048_frames_kernel(P2k p) {
   __shared__ float2 lds_all[W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W2K * kFftLdsFloat2PerWave;
   const v2f* w2 = reinterpret_cast<const v2f*>(tab + kTwiddleCount) + lane;
@@ -271,7 +271,7 @@ template <bool POLAR, int HS>
 __global__ __launch_bounds__(64 * W2K, 2) void istft2048_ola_kernel(P2kOla p) {
   constexpr int HOP = 256 * HS, R = 8 / HS, LEAD = 1024 / HOP;      // LEAD: blocks trimmed at the front
   __shared__ float2 lds_all[W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W2K * kFftLdsFloat2PerWave;
   const v2f* w2 = reinterpret_cast<const v2f*>(tab + kTwiddleCount) + lane;
@@ -406,7 +406,7 @@ __device__ __forceinline__ float contrast2k(float v, int mode, float eps) {
 template <int CMW>    // 1 / 2: channel-major output of a bank with that many passes (register window); 0: anything else
 __global__ __launch_bounds__(64 * W2K, 2) void stft2048_mel_kernel(P2kMel p) {
   extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W2K * kFftLdsFloat2PerWave;
   const v2f* w2 = reinterpret_cast<const v2f*>(tab + kTwiddleCount) + lane;

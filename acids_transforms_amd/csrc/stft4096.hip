@@ -123,7 +123,7 @@ constexpr int kLds4k = W4K * kFftLdsFloat2PerWave + kTwiddleCount + kTab4k;
 template <bool WRITE_PHASE>
 __global__ __launch_bounds__(64 * W4K, 2) void stft4096_fwd_kernel(P4k p) {
   __shared__ float2 lds_all[kLds4k];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W4K * kFftLdsFloat2PerWave;
   float2* t4 = tab + kTwiddleCount;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void spectrum_to_subffts4k(const float2* X, const flo
 template <bool POLAR>
 __global__ __launch_bounds__(64 * W4K, 2) void irfft4096_frames_kernel(P4k p) {
   __shared__ float2 lds_all[kLds4k];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W4K * kFftLdsFloat2PerWave;
   float2* t4 = tab + kTwiddleCount;
@@ -307,7 +307,7 @@ template <bool POLAR, int HS>
 __global__ __launch_bounds__(64 * W4K, 2) void istft4096_ola_kernel(P4kOla p) {
   constexpr int HOP = 512 * HS, R = 8 / HS, LEAD = 2048 / HOP;      // LEAD: blocks trimmed at the front
   __shared__ float2 lds_all[kLds4k];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W4K * kFftLdsFloat2PerWave;
   float2* t4 = tab + kTwiddleCount;

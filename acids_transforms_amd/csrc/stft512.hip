@@ -102,7 +102,7 @@ __device__ __forceinline__ void mirror256(const v2f (&v)[4], v2f (&p)[4], int la
 template <bool WRITE_PHASE>
 __global__ __launch_bounds__(64 * W5) void stft512_fwd_kernel(P5 p) {
   __shared__ float2 lds_all[W5 * kFftLdsFloat2PerWave];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   Twiddles tw;
   load_twiddles<false>(tw, p.tw, lane);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void load_split5(const P5& p, long long f, bool exist
 template <bool POLAR>
 __global__ __launch_bounds__(64 * W5) void irfft512_frames_kernel(P5 p) {
   __shared__ float2 lds_all[W5 * kFftLdsFloat2PerWave];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   Twiddles tw;
   load_twiddles<true>(tw, p.tw, lane);
@@ -300,7 +300,7 @@ template <bool POLAR, int HS>
 __global__ __launch_bounds__(64 * W5) void istft512_ola_kernel(P5Ola p) {
   constexpr int HOP = 64 * HS, R = 8 / HS, LEAD = 256 / HOP;
   __shared__ float2 lds_all[W5 * kFftLdsFloat2PerWave];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   const int par = lane & 1, u = lane >> 1;
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   Twiddles tw;
@@ -458,7 +458,7 @@ template <int CMW>    // 1 / 2: channel-major output of a bank with that many pa
 __global__ __launch_bounds__(64 * W5) void stft512_mel_kernel(P5Mel p) {
   __shared__ float2 lds_all[W5 * kFftLdsFloat2PerWave];
   extern __shared__ __attribute__((aligned(16))) float dyn5[];      // rows (two per wave), weights, lane tables
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float* rowa = dyn5 + (2 * wave) * p.row_floats;
   float* rowb = rowa + p.row_floats;

@@ -116,7 +116,7 @@ template <int K, bool WRITE_PHASE>
 __global__ __launch_bounds__(64 * WS) void stft_small_fwd_kernel(PSm p) {
   constexpr int M = 512 / K, Q = 8 / K, F = M + 1, PER = 64 / K;
   __shared__ float2 lds_all[WS * kFftLdsFloat2PerWave];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   Twiddles tw;
   load_twiddles<false>(tw, p.tw, lane);
@@ -192,7 +192,7 @@ template <int K, bool POLAR>
 __global__ __launch_bounds__(64 * WS) void irfft_small_frames_kernel(PSm p) {
   constexpr int N = 1024 / K, M = 512 / K, Q = 8 / K, F = M + 1, PER = 64 / K;
   __shared__ float2 lds_all[WS * kFftLdsFloat2PerWave];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   Twiddles tw;
   load_twiddles<true>(tw, p.tw, lane);
