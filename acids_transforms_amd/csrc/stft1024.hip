@@ -23,6 +23,13 @@
 #include "band_bank.h"
 #include "fft512.h"
 
+#ifndef AT_ISTFT_NT
+#define AT_ISTFT_NT 1
+#endif
+#ifndef AT_ISTFT_NTLOAD
+#define AT_ISTFT_NTLOAD 1      // spectra are read once: -1 ... -2 % (alternating A/B, tools/ab3.sh)
+#endif
+
 namespace at_hip {
 
 constexpr int N = 1024;
@@ -680,7 +687,13 @@ struct RawFrame<IN_GL> {
 __device__ __forceinline__ void load_raw(const InvParams& p, long long f, int lane, RawFrame<IN_COMPLEX>& q) {
   const f32x2* row = reinterpret_cast<const f32x2*>(p.X + f * F);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) q.d[m] = row[lane + 64 * m];
+  for (int m = 0; m < 8; ++m) {
+#if AT_ISTFT_NTLOAD
+    q.d[m] = __builtin_nontemporal_load(row + lane + 64 * m);
+#else
+    q.d[m] = row[lane + 64 * m];
+#endif
+  }
   // broadcast load; only lane 0 uses it.  A 4-byte load of the real part alone: as `row[512].x` it was an 8-byte
   // load whose dead upper register the allocator handed to the next instruction at once -- a write-after-write
   // hazard on a load just issued, i.e. `s_waitcnt vmcnt(0)` in the steady-state loop, draining both frames of lookahead.
@@ -846,12 +859,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc[m] = cadd(acc[m], v[m]);
   };
+  // finished hops leave through non-temporal stores: written once, read by nobody here (the pattern-only copy kernel
+  // of tools/ubench/stream_pattern2.hip gains 3-4 % from them: 0.717 -> 0.689 ms)
+  auto put_y = [&](float2* dst, float2 val) {
+#if AT_ISTFT_NT
+    __builtin_nontemporal_store((v2f){val.x, val.y}, reinterpret_cast<v2f*>(dst));
+#else
+    *dst = val;
+#endif
+  };
   auto emit = [&](long long j, const float2* env) {
     float2* dst = reinterpret_cast<float2*>(yclip + j * H);
 #pragma unroll
     for (int k = 0; k < HS; ++k) {
       const float2 e = env[lane + 64 * k];
-      dst[lane + 64 * k] = make_float2(acc[k].x / e.x, acc[k].y / e.y);
+      put_y(dst + lane + 64 * k, make_float2(acc[k].x / e.x, acc[k].y / e.y));
     }
   };
   // steady state: the envelope of a fully overlapped hop is the same for every frame, so its reciprocal is taken
@@ -860,7 +882,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS
   auto emit_fast = [&](long long j) {
     float2* dst = reinterpret_cast<float2*>(yclip + j * H);
 #pragma unroll
-    for (int k = 0; k < HS; ++k) dst[lane + 64 * k] = make_float2(acc[k].x * rcp[k].x, acc[k].y * rcp[k].y);
+    for (int k = 0; k < HS; ++k) put_y(dst + lane + 64 * k, make_float2(acc[k].x * rcp[k].x, acc[k].y * rcp[k].y));
   };
   auto advance = [&]() {   // one hop = HS register slots
 #pragma unroll
