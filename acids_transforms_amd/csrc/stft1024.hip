@@ -22,6 +22,7 @@
 
 #include "band_bank.h"
 #include "fft512.h"
+#include "run_plan.h"
 
 #ifndef AT_ISTFT_NT
 #define AT_ISTFT_NT 1
@@ -991,54 +992,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void irfft1024_frames_kernel(
 // host launchers (C++ linkage inside the library; the extern "C" ABI is capi.hip)
 // ---------------------------------------------------------------------------
 namespace at_hip {
-
-static inline int num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
-
-// wave slots the chip offers one kernel variant (occupancy x CUs), cached per variant by the caller
-template <typename K>
-static long long resident_waves(K kernel, int block_threads, size_t dyn_lds) {
-  struct Entry { const void* k; size_t lds; long long waves; };
-  static thread_local Entry cache[16];
-  static thread_local int n_cached = 0;
-  for (int i = 0; i < n_cached; ++i)
-    if (cache[i].k == (const void*)kernel && cache[i].lds == dyn_lds) return cache[i].waves;
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_threads, dyn_lds) != hipSuccess || nb <= 0) nb = 2;
-  const long long waves = (long long)nb * (block_threads / 64) * num_cus();
-  if (n_cached < 16) cache[n_cached++] = {(const void*)kernel, dyn_lds, waves};
-  return waves;
-}
-
-// Split each of the B clips' `units` (frames / hop slots) into equal runs, one wave per run.  Every wave of a
-// streaming kernel takes the same time, so the launch costs ceil(waves / slots) rounds of (run length +
-// per-run overhead): 4096 waves on 3072 slots is two rounds, the second one a third full -- pick the run
-// count that minimises rounds x run length instead of aiming at a fixed wave count.
-static long long plan_units_per_run(long long B, long long units, long long slots, long long min_units,
-                                    long long overhead_units) {
-  long long best_upr = units, best_cost = -1;
-  long long max_runs = units / (min_units > 0 ? min_units : 1);
-  if (max_runs < 1) max_runs = 1;
-  for (long long runs = 1; runs <= max_runs; ++runs) {
-    const long long upr = (units + runs - 1) / runs;
-    const long long waves = B * ((units + upr - 1) / upr);
-    const long long cost = ((waves + slots - 1) / slots) * (upr + overhead_units);
-    if (best_cost < 0 || cost < best_cost) {
-      best_cost = cost;
-      best_upr = upr;
-    }
-  }
-  return best_upr;
-}
 
 int launch_stft1024_fwd(const float* x, long long B, long long L, long long clip_stride, long long T, int hop,
                         int center, const float* window, const float2* tw, float2* out, float* phase,

@@ -25,6 +25,8 @@
 #include "fft512.h"
 #include "band_bank.h"
 #include "mel_gemm.h"   // C_* contrast codes
+#include "run_plan.h"
+#include <stdlib.h>
 
 namespace at_hip {
 
@@ -168,6 +170,170 @@ __global__ __launch_bounds__(64 * W2K, 3) void stft2048_fwd_kernel(P2k p) {
       if (WRITE_PHASE) prow[1024] = fast_atan2f(nyq.y, nyq.x);
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// forward, hop = 512 = N/4, center = True: the sliding-window / aligned-stream form of the n_fft-1024 kernel (round 3).
+// A wave walks a run of consecutive frames of one clip.  Register j of a lane holds x[s + 4 (lane + 64 j) .. + 3], so the
+// next frame is "registers j + 2 of the same lane": the raw samples stay in registers, shifted by two slots per frame,
+// and only the 512 new samples (two 16-byte loads per lane) are fetched -- 2 KB of loads per frame instead of 8 KB.
+// The spectrum leaves as ONE byte stream in 512-byte aligned blocks (stft1024.hip, template flag AL): rows are 8200
+// bytes, row f starts 8 f bytes past a 128-byte line; the output columns of both 512-point FFTs are rotated over the
+// lanes by rot = (f 1025) mod 64 = (rot + 1) mod 64 per frame, the radix-2 stage is lane-local and does not care, the
+// merge's twiddles (W1024^k / 2, W2048^k) and mirror lane follow the column, and block 16 of a frame (the tail of
+// register 15 and the Nyquist bin) is carried into the next frame's block 0.  Sixteen full-line non-temporal stores per
+// frame (a seventeenth every 64 frames).
+// ---------------------------------------------------------------------------
+struct P2kRun {
+  const float* x;
+  const float* window;
+  const float2* tw;
+  const float2* tw2k;
+  float2* X;
+  long long B, L, clip_stride, T, runs_per_clip, frames_per_run;
+};
+
+__device__ __forceinline__ void mirror1024_rot(const v2f (&v)[16], v2f (&p)[16], int lane, int rot, int col) {
+  const int src = (2 * rot - lane) & 63;
+  v2f q[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    q[m].x = __shfl(v[m].x, src, 64);
+    q[m].y = __shfl(v[m].y, src, 64);
+  }
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const v2f a = q[15 - m];
+    const v2f b = q[(16 - m) & 15];
+    p[m] = (col == 0) ? b : a;
+  }
+}
+
+// 256 samples (one register slot of the wave) starting at original index i0 of the clip, reflect-padded
+__device__ __forceinline__ float4 load_slot2k(const float* clip, long long L, long long i0, int lane) {
+  const long long i = i0 + 4 * lane;
+  if (i0 >= 0 && i0 + 256 <= L) return *reinterpret_cast<const float4*>(clip + i);     // clip base 16-byte aligned (launcher)
+  return make_float4(clip[reflect2k(i, L)], clip[reflect2k(i + 1, L)], clip[reflect2k(i + 2, L)], clip[reflect2k(i + 3, L)]);
+}
+
+constexpr int W2KR = 8;     // waves per block of the run kernel: two blocks per CU, four waves per SIMD (126 VGPRs)
+__global__ __launch_bounds__(64 * W2KR, 4) void stft2048_run_fwd_kernel(P2kRun p) {
+  __shared__ float2 lds_all[W2KR * kFftLdsFloat2PerWave + kTwiddleCount + 1024 + 1024];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* tab = lds_all + W2KR * kFftLdsFloat2PerWave;
+  float2* w2tab = tab + kTwiddleCount;
+  float4* wintab = reinterpret_cast<float4*>(w2tab + 1024);          // analysis window, 512 float4
+  for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * W2KR) tab[i] = twiddle_for_lds<false>(p.tw, i);
+  for (int i = threadIdx.x; i < 1024; i += 64 * W2KR) w2tab[i] = p.tw2k[i];
+  for (int i = threadIdx.x; i < 512; i += 64 * W2KR) wintab[i] = reinterpret_cast<const float4*>(p.window)[i];
+  __syncthreads();
+
+  const long long run = (long long)blockIdx.x * W2KR + wave;
+  const long long b = run / p.runs_per_clip;
+  if (b >= p.B) return;
+  const long long r = run - b * p.runs_per_clip;
+  const long long t0 = r * p.frames_per_run;
+  long long t1 = t0 + p.frames_per_run;
+  if (t1 > p.T) t1 = p.T;
+  if (t0 >= t1) return;
+  const float* clip = p.x + b * p.clip_stride;
+  const long long L = p.L;
+  const LdsTwiddles<false> tw = {tab, lane};
+  const v2f hh = {0.5f, 0.5f};
+
+  float4 raw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) raw[j] = load_slot2k(clip, L, t0 * 512 - 1024 + 256 * j, lane);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(raw[j].x), "+v"(raw[j].y), "+v"(raw[j].z), "+v"(raw[j].w));
+
+  const long long e0 = (b * p.T + t0) * F2K;
+  int rot = (int)(e0 & 63);
+  float2* sp = p.X + (e0 - rot) + lane;
+  v2f carry = {0.f, 0.f};
+  bool head = true;
+  auto put = [&](float2* dst, v2f val) { __builtin_nontemporal_store(val, reinterpret_cast<v2f*>(dst)); };
+
+  auto frame_body = [&](const float4 (&fresh)[2]) {
+    v2f ze[8], zo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 w = wintab[lane + 64 * j];
+      ze[j] = (v2f){raw[j].x * w.x, raw[j].y * w.y};
+      zo[j] = (v2f){raw[j].z * w.z, raw[j].w * w.w};
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) raw[j] = raw[j + 2];
+    raw[6] = fresh[0];
+    raw[7] = fresh[1];
+    const int col = (lane - rot) & 63;
+    fft512<false>(ze, tw, lds, lane, col);
+    fft512<false>(zo, tw, lds, lane, col);
+    const LdsTwiddles<false> twc = {tab, col};
+    v2f z[16];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const v2f t = cmul_v(zo[m], twc.getr(m));
+      const v2f e = ze[m] * hh;
+      z[m] = e + t;
+      z[m + 8] = e - t;
+    }
+    v2f pm[16];
+    mirror1024_rot(z, pm, lane, rot, col);
+    const v2f nyq = {2.0f * (z[0].x - z[0].y), 0.0f};          // X[1024], meaningful on the lane whose column is 0
+    const v2f* w2 = reinterpret_cast<const v2f*>(w2tab) + col;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const v2f e = add_conj(z[m], pm[m]);
+      const v2f d = sub_conj(z[m], pm[m]);
+      z[m] = add_mi(e, cmul_v(d, lds_read_single(w2 + 64 * m)));
+    }
+    const bool lo = lane < rot;
+    const v2f s0 = lo ? carry : z[0];
+    if (head) {
+      if (!lo) put(sp, s0);
+      head = false;
+    } else {
+      put(sp, s0);
+    }
+#pragma unroll
+    for (int j = 1; j < 16; ++j) put(sp + 64 * j, lo ? z[j - 1] : z[j]);
+    carry = lo ? z[15] : nyq;
+    if (rot == 63) {
+      put(sp + 1024, carry);
+      sp += 1088;
+      rot = 0;
+    } else {
+      sp += 1024;
+      ++rot;
+    }
+  };
+
+  long long t = t0;
+  long long t_fast_end = (L >= 1536) ? (L - 1536) / 512 + 1 : 0;     // first t whose successor's new samples need reflection
+  if (t_fast_end > t1 - 1) t_fast_end = t1 - 1;
+  if (t < t_fast_end) {
+    const float4* nsrc = reinterpret_cast<const float4*>(clip + t * 512 + 1024) + lane;
+    for (; t < t_fast_end; ++t) {
+      float4 fresh[2];
+      fresh[0] = nsrc[0];
+      fresh[1] = nsrc[64];
+      nsrc += 128;
+      frame_body(fresh);
+    }
+  }
+  for (; t < t1; ++t) {
+    float4 fresh[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (t + 1 < t1) {
+      fresh[0] = load_slot2k(clip, L, t * 512 + 1024, lane);
+      fresh[1] = load_slot2k(clip, L, t * 512 + 1280, lane);
+    }
+    frame_body(fresh);
+  }
+  if (lane < rot) put(sp, carry);
 }
 
 __device__ __forceinline__ void sincos_big2k(float phase, float& s, float& c) {
@@ -671,6 +837,20 @@ int launch_stft2048_fwd(const float* x, long long B, long long L, long long clip
   P2k p = {};
   p.x = x; p.window = window; p.tw = tw; p.tw2k = tw2k; p.X = out; p.phase_out = phase;
   p.L = L; p.clip_stride = clip_stride; p.T = T; p.total_frames = nframes; p.hop = hop; p.center = center;
+  // the sliding-window / aligned-stream kernel: torch.stft's framing at hop n/4, 16-byte aligned clips, a 512-byte
+  // aligned output (torch allocations are), no phase side output
+  if (center && hop == 512 && !phase && L >= 2048 && (clip_stride & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
+      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 15) == 0 && !getenv("ACIDS_STFT2048_FRAMES")) {
+    P2kRun q = {};
+    q.x = x; q.window = window; q.tw = tw; q.tw2k = tw2k; q.X = out;
+    q.B = B; q.L = L; q.clip_stride = clip_stride; q.T = T;
+    const long long slots = resident_waves(stft2048_run_fwd_kernel, 64 * W2KR, 0);
+    q.frames_per_run = plan_units_per_run(B, T, slots, 8, 1);
+    q.runs_per_clip = (T + q.frames_per_run - 1) / q.frames_per_run;
+    const long long waves = B * q.runs_per_clip;
+    hipLaunchKernelGGL(stft2048_run_fwd_kernel, dim3((unsigned)((waves + W2KR - 1) / W2KR)), dim3(64 * W2KR), 0, stream, q);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   p.frames_per_block = frames_per_block_2k(nframes);
   const long long blocks = (nframes + p.frames_per_block - 1) / p.frames_per_block;
   if (phase) hipLaunchKernelGGL(stft2048_fwd_kernel<true>, dim3((unsigned)blocks), dim3(64 * W2K), 0, stream, p);

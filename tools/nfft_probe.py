@@ -10,7 +10,7 @@ B, L = 1024, 176400
 x = torch.randn(B, L, device=dev) * 0.1
 
 
-def timeit(fn, n=5, warm=2):
+def timeit(fn, n=int(os.environ.get("PERF_N", "5")), warm=int(os.environ.get("PERF_WARM", "2"))):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
