@@ -22,6 +22,8 @@
 #include "../../include/acids_hip.h"
 #include "fastmath.h"
 #include "fft512.h"
+#include "run_plan.h"
+#include <stdlib.h>
 
 namespace at_hip {
 
@@ -188,6 +190,191 @@ __global__ __launch_bounds__(64 * W4K, 2) void stft4096_fwd_kernel(P4k p) {
       if (WRITE_PHASE) prow[2048] = fast_atan2f(nyq.y, nyq.x);
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// forward, hop = 1024 = N/4, center = True: sliding window in registers + aligned stream stores (round 3; the scheme of
+// stft1024.hip's AL kernel and stft2048.hip's run kernel).  Register slot j of a lane holds x[s + 8 (lane + 64 j) .. + 7]
+// (two float4): the next frame is "slots j + 2 of the same lane", so the raw samples stay in registers and only the
+// 1024 new samples (four 16-byte loads per lane) are fetched per frame -- 4 KB instead of 16 KB.  Rows are 16 392 bytes
+// (8 f bytes past a 128-byte line): the output columns of the four 512-point FFTs are rotated over the lanes by rot =
+// (f 2049) mod 64, the radix-4 stage is lane-local, the twiddles of the radix-4 stage and of the merge and the mirror
+// lane follow the column, block 32 of a frame (the tail of register 31, then the Nyquist bin) is carried into the next
+// frame's block 0: 32 full-line non-temporal stores per frame.
+// ---------------------------------------------------------------------------
+struct P4kRun {
+  const float* x;
+  const float* window;
+  const float2* tw;
+  const float2* tw4k;
+  float2* X;
+  long long B, L, clip_stride, T, runs_per_clip, frames_per_run;
+};
+
+__device__ __forceinline__ void mirror2048_rot(const v2f (&v)[32], v2f (&p)[32], int lane, int rot, int col) {
+  const int src = (2 * rot - lane) & 63;
+  v2f q[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    q[m].x = __shfl(v[m].x, src, 64);
+    q[m].y = __shfl(v[m].y, src, 64);
+  }
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    const v2f a = q[31 - m];
+    const v2f b = q[(32 - m) & 31];
+    p[m] = (col == 0) ? b : a;
+  }
+}
+
+// 512 samples (one register slot of the wave) starting at original index i0 of the clip, reflect-padded
+__device__ __forceinline__ void load_slot4k(const float* clip, long long L, long long i0, int lane, float4& a, float4& b) {
+  const long long i = i0 + 8 * lane;
+  if (i0 >= 0 && i0 + 512 <= L) {                                 // clip base 16-byte aligned (launcher)
+    a = *reinterpret_cast<const float4*>(clip + i);
+    b = *reinterpret_cast<const float4*>(clip + i + 4);
+    return;
+  }
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = clip[reflect4k(i + c, L)];
+  a = make_float4(v[0], v[1], v[2], v[3]);
+  b = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+constexpr int kLds4kRun = kLds4k + 2048;          // + the analysis window (1024 float4)
+
+__global__ __launch_bounds__(64 * W4K, 2) void stft4096_run_fwd_kernel(P4kRun p) {
+  __shared__ float2 lds_all[kLds4kRun];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* tab = lds_all + W4K * kFftLdsFloat2PerWave;
+  float2* t4 = tab + kTwiddleCount;
+  float4* wintab = reinterpret_cast<float4*>(t4 + kTab4k);
+  for (int i = threadIdx.x; i < 1024; i += 64 * W4K) wintab[i] = reinterpret_cast<const float4*>(p.window)[i];
+  stage_tables4k<false>(p.tw, p.tw4k, tab, t4);       // ends with __syncthreads()
+
+  const long long run = (long long)blockIdx.x * W4K + wave;
+  const long long b = run / p.runs_per_clip;
+  if (b >= p.B) return;
+  const long long r = run - b * p.runs_per_clip;
+  const long long t0 = r * p.frames_per_run;
+  long long t1 = t0 + p.frames_per_run;
+  if (t1 > p.T) t1 = p.T;
+  if (t0 >= t1) return;
+  const float* clip = p.x + b * p.clip_stride;
+  const long long L = p.L;
+  const LdsTwiddles<false> tw = {tab, lane};
+  const v2f hh = {0.5f, 0.5f};
+
+  float4 ra[8], rb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) load_slot4k(clip, L, t0 * 1024 - 2048 + 512 * j, lane, ra[j], rb[j]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    asm volatile("" : "+v"(ra[j].x), "+v"(ra[j].y), "+v"(ra[j].z), "+v"(ra[j].w));
+    asm volatile("" : "+v"(rb[j].x), "+v"(rb[j].y), "+v"(rb[j].z), "+v"(rb[j].w));
+  }
+
+  const long long e0 = (b * p.T + t0) * F4K;
+  int rot = (int)(e0 & 63);
+  float2* sp = p.X + (e0 - rot) + lane;
+  v2f carry = {0.f, 0.f};
+  bool head = true;
+  auto put = [&](float2* dst, v2f val) { __builtin_nontemporal_store(val, reinterpret_cast<v2f*>(dst)); };
+
+  auto frame_body = [&](const float4 (&fa)[2], const float4 (&fb)[2]) {
+    v2f z0[8], z1[8], z2[8], z3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 wa = wintab[2 * (lane + 64 * j)];
+      const float4 wb = wintab[2 * (lane + 64 * j) + 1];
+      z0[j] = (v2f){ra[j].x * wa.x, ra[j].y * wa.y};
+      z1[j] = (v2f){ra[j].z * wa.z, ra[j].w * wa.w};
+      z2[j] = (v2f){rb[j].x * wb.x, rb[j].y * wb.y};
+      z3[j] = (v2f){rb[j].z * wb.z, rb[j].w * wb.w};
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      ra[j] = ra[j + 2];
+      rb[j] = rb[j + 2];
+    }
+    ra[6] = fa[0]; rb[6] = fb[0];
+    ra[7] = fa[1]; rb[7] = fb[1];
+    const int col = (lane - rot) & 63;
+    fft512<false>(z0, tw, lds, lane, col);
+    fft512<false>(z1, tw, lds, lane, col);
+    fft512<false>(z2, tw, lds, lane, col);
+    fft512<false>(z3, tw, lds, lane, col);
+    const v2f* wh = reinterpret_cast<const v2f*>(t4) + col;            // wh[64 m] = W4096^(col + 64 m) / 2
+    const v2f* wr = reinterpret_cast<const v2f*>(t4 + 2048) + col;     // wr[(r - 1) 512 + 64 m] = W2048^(r (col + 64 m))
+    v2f z[32];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const v2f t1 = cmul_v(z1[m], wr[64 * m]);
+      const v2f t2 = cmul_v(z2[m], wr[512 + 64 * m]);
+      const v2f t3 = cmul_v(z3[m], wr[1024 + 64 * m]);
+      const v2f a = z0[m] + t2, bb = z0[m] - t2, c = t1 + t3, d = t1 - t3;
+      z[m] = a + c;
+      z[m + 16] = a - c;
+      z[m + 8] = add_mi(bb, d);
+      z[m + 24] = add_pi(bb, d);
+    }
+    v2f pm[32];
+    mirror2048_rot(z, pm, lane, rot, col);
+    const v2f nyq = {z[0].x - z[0].y, 0.0f};                           // X[2048], on the lane whose column is 0
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      const v2f e = add_conj(z[m], pm[m]);
+      const v2f d = sub_conj(z[m], pm[m]);
+      z[m] = scale_add_mi(e, hh, cmul_v(d, wh[64 * m]));
+    }
+    const bool lo = lane < rot;
+    const v2f s0 = lo ? carry : z[0];
+    if (head) {
+      if (!lo) put(sp, s0);
+      head = false;
+    } else {
+      put(sp, s0);
+    }
+#pragma unroll
+    for (int j = 1; j < 32; ++j) put(sp + 64 * j, lo ? z[j - 1] : z[j]);
+    carry = lo ? z[31] : nyq;
+    if (rot == 63) {
+      put(sp + 2048, carry);
+      sp += 2112;
+      rot = 0;
+    } else {
+      sp += 2048;
+      ++rot;
+    }
+  };
+
+  long long t = t0;
+  long long t_fast_end = (L >= 3072) ? (L - 3072) / 1024 + 1 : 0;     // first t whose successor's new samples need reflection
+  if (t_fast_end > t1 - 1) t_fast_end = t1 - 1;
+  if (t < t_fast_end) {
+    const float4* nsrc = reinterpret_cast<const float4*>(clip + t * 1024 + 2048) + 2 * lane;
+    for (; t < t_fast_end; ++t) {
+      float4 fa[2], fb[2];
+      fa[0] = nsrc[0];   fb[0] = nsrc[1];
+      fa[1] = nsrc[128]; fb[1] = nsrc[129];
+      nsrc += 256;
+      frame_body(fa, fb);
+    }
+  }
+  for (; t < t1; ++t) {
+    float4 fa[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float4 fb[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (t + 1 < t1) {
+      load_slot4k(clip, L, t * 1024 + 2048, lane, fa[0], fb[0]);
+      load_slot4k(clip, L, t * 1024 + 2560, lane, fa[1], fb[1]);
+    }
+    frame_body(fa, fb);
+  }
+  if (lane < rot) put(sp, carry);
 }
 
 __device__ __forceinline__ void sincos_big4k(float phase, float& s, float& c) {
@@ -422,6 +609,20 @@ int launch_stft4096_fwd(const float* x, long long B, long long L, long long clip
   P4k p = {};
   p.x = x; p.window = window; p.tw = tw; p.tw4k = tw4k; p.X = out; p.phase_out = phase;
   p.L = L; p.clip_stride = clip_stride; p.T = T; p.total_frames = nframes; p.hop = hop; p.center = center;
+  // the sliding-window / aligned-stream kernel: torch.stft's framing at hop n/4, 16-byte aligned clips, a 512-byte
+  // aligned output, no phase side output
+  if (center && hop == 1024 && !phase && L >= 4096 && (clip_stride & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
+      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 15) == 0 && !getenv("ACIDS_STFT4096_FRAMES")) {
+    P4kRun q = {};
+    q.x = x; q.window = window; q.tw = tw; q.tw4k = tw4k; q.X = out;
+    q.B = B; q.L = L; q.clip_stride = clip_stride; q.T = T;
+    const long long slots = resident_waves(stft4096_run_fwd_kernel, 64 * W4K, 0);
+    q.frames_per_run = plan_units_per_run(B, T, slots, 8, 1);
+    q.runs_per_clip = (T + q.frames_per_run - 1) / q.frames_per_run;
+    const long long waves = B * q.runs_per_clip;
+    hipLaunchKernelGGL(stft4096_run_fwd_kernel, dim3((unsigned)((waves + W4K - 1) / W4K)), dim3(64 * W4K), 0, stream, q);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   p.frames_per_block = frames_per_block_4k(nframes);
   const long long blocks = (nframes + p.frames_per_block - 1) / p.frames_per_block;
   if (phase) hipLaunchKernelGGL(stft4096_fwd_kernel<true>, dim3((unsigned)blocks), dim3(64 * W4K), 0, stream, p);

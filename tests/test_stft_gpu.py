@@ -443,3 +443,31 @@ def test_register_core_sizes_512_and_2048(dev, n):
     assert rel_max(cpu(rs.invert(Xf)), O.rt_invert(Xfr, O.hann_window(n)).numpy()) < TOL
     assert rel_max(cpu(ops.irfft_frames(None, rs.inv_window[:n], n, mag=Xf.abs(), phase=Xf.angle())),
                    O.rt_invert(Xfr, O.hann_window(n)).numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_sliding_aligned_forward_2048_4096_full_batch(dev, n, monkeypatch):
+    """The hop = n/4 forward of n_fft 2048 / 4096 (sliding window in registers + aligned stream stores, round 3) at the
+    size where a wave's run is long enough for the column rotation to wrap inside it (1024 clips x 4 s: 87 / 44 frames
+    per run): clips {0, 511, 1023} against the oracle, and the whole tensor against the frame-at-a-time kernel."""
+    B, L, h = 1024, 176400, n // 4
+    g = torch.Generator().manual_seed(n + 5)
+    x = torch.randn(B, L, generator=g) * 0.1
+    st = A.STFT(n_fft=n, hop_length=h).to(dev)
+    xd = x.to(dev)
+    X = st(xd)
+    ids = [0, 511, 1023]
+    Xr = O.stft_forward(x[ids], O.hann_window(n), n, h)
+    assert X.shape[1:] == Xr.shape[1:]
+    assert rel_max(cpu(X[ids]), Xr.numpy()) < TOL
+    monkeypatch.setenv("ACIDS_STFT%d_FRAMES" % n, "1")
+    Xf = st(xd)
+    monkeypatch.delenv("ACIDS_STFT%d_FRAMES" % n)
+    scale = float(torch.view_as_real(Xf).abs().max())
+    assert float((torch.view_as_real(X) - torch.view_as_real(Xf)).abs().max()) < 3e-6 * scale
+    del X, Xf
+    # a clip length that is not a multiple of the hop, few clips (short runs: heads and carried tails everywhere), DGT window
+    for (Bs, Ls) in [(3, 40 * n + 4 * 37), (2, 9 * n), (1, 300 * h + 8)]:
+        xs = torch.randn(Bs, Ls, generator=g)
+        d = A.DGT(n_fft=n, hop_length=h).to(dev)
+        assert rel_max(cpu(d(xs.to(dev))), O.stft_forward(xs, O.gauss_window(n), n, h).numpy()) < TOL, (Bs, Ls)
