@@ -21,6 +21,8 @@
 #include "fft512.h"
 #include "band_bank.h"
 #include "mel_gemm.h"   // C_* contrast codes
+#include "run_plan.h"
+#include <stdlib.h>
 
 namespace at_hip {
 
@@ -167,6 +169,207 @@ __global__ __launch_bounds__(64 * W5) void stft512_fwd_kernel(P5 p) {
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// forward, hop = 128 = N/4, center = True: sliding window in registers + aligned stream stores (round 3; the scheme of
+// stft1024.hip's AL kernel).  A wave walks consecutive frame PAIRS (2 i, 2 i + 1) of one clip; even lanes hold the
+// samples of the first frame, odd lanes of the second (register slot j = 64 samples), so the next pair is "slots j + 4
+// of the same lane": four 8-byte loads per lane and pair instead of eight.  Rows are 2056 bytes (8 f bytes past a
+// 128-byte line).  The FFT's output columns are rotated over the lanes by rot = (f 257) mod 64 of the pair's FIRST
+// frame; after the un-mixing every lane holds the same columns of both frames, so the second frame -- which needs
+// rot + 1 -- is moved up one lane (nine ds_bpermute: its four registers and its Nyquist bin) and then leaves exactly
+// like a frame of its own: four full-line non-temporal stores per frame, block 4 (the tail of register 3, then the
+// Nyquist bin) carried into the next frame's block 0.
+// ---------------------------------------------------------------------------
+struct P5Run {
+  const float* x;
+  const float* window;
+  const float2* tw;
+  const float2* tw512;
+  float2* X;
+  long long B, L, clip_stride, T, runs_per_clip, pairs_per_run;
+};
+
+__device__ __forceinline__ void mirror256_rot(const v2f (&v)[4], v2f (&p)[4], int lane, int rot, int col) {
+  const int src = (2 * rot - lane) & 63;
+  v2f q[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    q[m].x = __shfl(v[m].x, src, 64);
+    q[m].y = __shfl(v[m].y, src, 64);
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const v2f a = q[3 - m];
+    const v2f b = q[(4 - m) & 3];
+    p[m] = (col == 0) ? b : a;
+  }
+}
+
+// two samples of a frame that starts at original index s (reflect-padded)
+__device__ __forceinline__ float2 load_pair5(const float* clip, long long L, long long i, bool interior) {
+  if (interior) return *reinterpret_cast<const float2*>(clip + i);        // clip base 8-byte aligned, i even
+  return make_float2(clip[reflect5(i, L)], clip[reflect5(i + 1, L)]);
+}
+
+constexpr int W5R = 8;      // waves per block of the run kernel
+
+__global__ __launch_bounds__(64 * W5R, 4) void stft512_run_fwd_kernel(P5Run p) {
+  __shared__ float2 lds_all[W5R * kFftLdsFloat2PerWave + 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int par = lane & 1, u = lane >> 1;
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* w5tab = lds_all + W5R * kFftLdsFloat2PerWave;                  // W512^k, k = 0 .. 255
+  for (int i = threadIdx.x; i < 256; i += 64 * W5R) w5tab[i] = p.tw512[i];
+  __syncthreads();
+  Twiddles tw;
+  load_twiddles<false>(tw, p.tw, lane);
+  float2 win[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) win[j] = reinterpret_cast<const float2*>(p.window)[u + 32 * j];
+
+  const long long run = (long long)blockIdx.x * W5R + wave;
+  const long long b = run / p.runs_per_clip;
+  if (b >= p.B) return;
+  const long long r = run - b * p.runs_per_clip;
+  const long long T = p.T, L = p.L;
+  const long long n_pairs = (T + 1) / 2;
+  const long long i0 = r * p.pairs_per_run;
+  long long i1 = i0 + p.pairs_per_run;
+  if (i1 > n_pairs) i1 = n_pairs;
+  if (i0 >= i1) return;
+  const float* clip = p.x + b * p.clip_stride;
+  const v2f hh = {0.5f, 0.5f};
+
+  // this lane's frame of pair i: f = 2 i + par, starting at original sample 128 f - 256; slot j = samples 64 j .. + 63
+  float2 raw[8];
+  {
+    const long long f = 2 * i0 + par;
+    const long long s = 128 * f - 256;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long i = s + 2 * (u + 32 * j);
+      const bool in = (s + 64 * j >= 0) && (s + 64 * j + 64 <= L);
+      raw[j] = (f < T) ? load_pair5(clip, L, i, in) : make_float2(0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(raw[j].x), "+v"(raw[j].y));
+
+  const long long e0 = (b * T + 2 * i0) * F5;
+  int rot = (int)(e0 & 63);
+  float2* sp = p.X + (e0 - rot) + lane;
+  v2f carry = {0.f, 0.f};
+  bool head = true;
+  auto put = [&](float2* dst, v2f val) { __builtin_nontemporal_store(val, reinterpret_cast<v2f*>(dst)); };
+  // one frame's four registers (columns already rotated by the current `rot`) and Nyquist bin (on lane rot) into the stream
+  auto emit_frame = [&](const v2f (&z)[4], v2f nyq) {
+    const bool lo = lane < rot;
+    const v2f s0 = lo ? carry : z[0];
+    if (head) {
+      if (!lo) put(sp, s0);
+      head = false;
+    } else {
+      put(sp, s0);
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j) put(sp + 64 * j, lo ? z[j - 1] : z[j]);
+    carry = lo ? z[3] : nyq;
+    if (rot == 63) {
+      put(sp + 256, carry);
+      sp += 320;
+      rot = 0;
+    } else {
+      sp += 256;
+      ++rot;
+    }
+  };
+
+  auto pair_body = [&](const float2 (&fresh)[4], bool has_b) {
+    v2f y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = (v2f){raw[j].x * win[j].x, raw[j].y * win[j].y};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = raw[j + 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[4 + j] = fresh[j];
+    const int col = (lane - rot) & 63;
+    fft512<false>(y, tw, lds, lane, col);
+    const v2f* w5 = reinterpret_cast<const v2f*>(w5tab) + col;             // w5[64 m] = W512^(col + 64 m)
+    v2f ha[4], hb[4], wk[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      wk[m] = lds_read_single(w5 + 64 * m);
+      const v2f sm = (y[m] + y[m + 4]) * hh;              // A[k]
+      const v2f d = (y[m] - y[m + 4]) * hh;               // W512^k B[k]
+      ha[m] = sm * hh;                                     // A / 2
+      hb[m] = cmul_conj_v(d, wk[m]) * hh;                  // B / 2
+    }
+    v2f pa[4], pb[4];
+    mirror256_rot(ha, pa, lane, rot, col);
+    mirror256_rot(hb, pb, lane, rot, col);
+    v2f xa[4], xb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      xa[m] = add_mi(add_conj(ha[m], pa[m]), cmul_v(sub_conj(ha[m], pa[m]), wk[m]));
+      xb[m] = add_mi(add_conj(hb[m], pb[m]), cmul_v(sub_conj(hb[m], pb[m]), wk[m]));
+    }
+    const v2f na = {2.0f * (ha[0].x - ha[0].y), 0.0f};     // X_A[256], on the lane whose column is 0 (= lane rot)
+    const float nbx = 2.0f * (hb[0].x - hb[0].y);
+    emit_frame(xa, na);
+    if (has_b) {
+      // the second frame one lane up: its columns then sit where a frame with rotation rot + 1 wants them
+      const int src = (lane - 1) & 63;
+      v2f xs[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        xs[m].x = __shfl(xb[m].x, src, 64);
+        xs[m].y = __shfl(xb[m].y, src, 64);
+      }
+      const v2f nb = {__shfl(nbx, src, 64), 0.0f};
+      emit_frame(xs, nb);
+    }
+  };
+
+  long long i = i0;
+  // pairs whose successor pair (frames 2 i + 2, 2 i + 3) exists entirely and takes its new samples from inside the clip
+  long long i_fast_end = 0;
+  if (L >= 256 + 128 * 3) {
+    // frame f's new samples are [128 f, 128 f + 256): need 128 (2 i + 3) + 256 <= L and 2 i + 3 <= T - 1
+    long long lim = (L - 256) / 128;                 // largest f with 128 f + 256 <= L
+    if (lim > T - 1) lim = T - 1;
+    i_fast_end = (lim - 3) / 2 + 1;                  // pairs i with 2 i + 3 <= lim
+    if (lim < 3) i_fast_end = 0;
+  }
+  if (i_fast_end > i1 - 1) i_fast_end = i1 - 1;
+  if (i < i_fast_end) {
+    const float2* nsrc = reinterpret_cast<const float2*>(clip + 128 * (2 * (i + 1) + par)) + u;
+    for (; i < i_fast_end; ++i) {
+      float2 fresh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fresh[j] = nsrc[32 * j];
+      nsrc += 128;                                    // two hops = 256 samples
+      pair_body(fresh, true);
+    }
+  }
+  for (; i < i1; ++i) {
+    float2 fresh[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    if (i + 1 < i1) {
+      const long long f = 2 * (i + 1) + par;
+      if (f < T) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long long s = 128 * f + 64 * j;       // slot 4 + j of frame f: samples 128 f - 256 + 64 (4 + j) ..
+          fresh[j] = load_pair5(clip, L, s + 2 * u, s >= 0 && s + 64 <= L);
+        }
+      }
+    }
+    pair_body(fresh, 2 * i + 1 < T);
+  }
+  if (lane < rot) put(sp, carry);
 }
 
 __device__ __forceinline__ void sincos_big5(float phase, float& s, float& c) {
@@ -698,6 +901,21 @@ int launch_stft512_fwd(const float* x, long long B, long long L, long long clip_
   P5 p = {};
   p.x = x; p.window = window; p.tw = tw; p.tw512 = tw512; p.X = out; p.phase_out = phase;
   p.L = L; p.clip_stride = clip_stride; p.T = T; p.total_frames = nframes; p.hop = hop; p.center = center;
+  // the sliding-window / aligned-stream kernel: torch.stft's framing at hop n/4, 8-byte aligned clips, a 512-byte aligned
+  // output, no phase side output
+  if (center && hop == 128 && !phase && L >= 512 && (clip_stride & 1) == 0 && (((uintptr_t)x) & 7) == 0 &&
+      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 7) == 0 && !getenv("ACIDS_STFT512_FRAMES")) {
+    P5Run q = {};
+    q.x = x; q.window = window; q.tw = tw; q.tw512 = tw512; q.X = out;
+    q.B = B; q.L = L; q.clip_stride = clip_stride; q.T = T;
+    const long long slots = resident_waves(stft512_run_fwd_kernel, 64 * W5R, 0);
+    const long long pairs = (T + 1) / 2;
+    q.pairs_per_run = plan_units_per_run(B, pairs, slots, 8, 1);
+    q.runs_per_clip = (pairs + q.pairs_per_run - 1) / q.pairs_per_run;
+    const long long waves = B * q.runs_per_clip;
+    hipLaunchKernelGGL(stft512_run_fwd_kernel, dim3((unsigned)((waves + W5R - 1) / W5R)), dim3(64 * W5R), 0, stream, q);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   const long long npairs = (nframes + 1) / 2;
   p.pairs_per_block = pairs_per_block_5(npairs);
   const long long blocks = (npairs + p.pairs_per_block - 1) / p.pairs_per_block;

@@ -471,3 +471,31 @@ def test_sliding_aligned_forward_2048_4096_full_batch(dev, n, monkeypatch):
         xs = torch.randn(Bs, Ls, generator=g)
         d = A.DGT(n_fft=n, hop_length=h).to(dev)
         assert rel_max(cpu(d(xs.to(dev))), O.stft_forward(xs, O.gauss_window(n), n, h).numpy()) < TOL, (Bs, Ls)
+
+
+def test_sliding_aligned_forward_512_full_batch(dev, monkeypatch):
+    """n_fft 512 at hop 128: frame PAIRS per wave FFT, sliding window, aligned stream stores with the second frame of
+    a pair moved up one lane (round 3).  Full batch (345-pair runs: the rotation wraps inside them) against the oracle
+    and the frame-pair-at-a-time kernel; then odd / even frame counts, short clips, few clips (short runs), DGT."""
+    n, h = 512, 128
+    B, L = 1024, 176400
+    g = torch.Generator().manual_seed(517)
+    x = torch.randn(B, L, generator=g) * 0.1
+    st = A.STFT(n_fft=n, hop_length=h).to(dev)
+    xd = x.to(dev)
+    X = st(xd)
+    ids = [0, 511, 1023]
+    Xr = O.stft_forward(x[ids], O.hann_window(n), n, h)
+    assert X.shape[1:] == Xr.shape[1:]
+    assert rel_max(cpu(X[ids]), Xr.numpy()) < TOL
+    monkeypatch.setenv("ACIDS_STFT512_FRAMES", "1")
+    Xf = st(xd)
+    monkeypatch.delenv("ACIDS_STFT512_FRAMES")
+    scale = float(torch.view_as_real(Xf).abs().max())
+    assert float((torch.view_as_real(X) - torch.view_as_real(Xf)).abs().max()) < 3e-6 * scale
+    del X, Xf
+    for (Bs, Ls) in [(3, 40 * n + 2 * 37), (2, 9 * n), (1, 300 * h + 8), (5, 512), (4, 640), (2, 33 * h), (1, 34 * h + 6)]:
+        xs = torch.randn(Bs, Ls, generator=g)
+        for cls, w in ((A.DGT, O.gauss_window(n)), (A.STFT, O.hann_window(n))):
+            m = cls(n_fft=n, hop_length=h).to(dev)
+            assert rel_max(cpu(m(xs.to(dev))), O.stft_forward(xs, w, n, h).numpy()) < TOL, (Bs, Ls)
