@@ -436,13 +436,21 @@ struct P2kOla {
 template <bool POLAR, int HS>
 __global__ __launch_bounds__(64 * W2K, 2) void istft2048_ola_kernel(P2kOla p) {
   constexpr int HOP = 256 * HS, R = 8 / HS, LEAD = 1024 / HOP;      // LEAD: blocks trimmed at the front
-  __shared__ float2 lds_all[W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024];
+  __shared__ float2 lds_all[W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024 + 1024];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W2K * kFftLdsFloat2PerWave;
   const v2f* w2 = reinterpret_cast<const v2f*>(tab + kTwiddleCount) + lane;
   for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * W2K) tab[i] = twiddle_for_lds<true>(p.tw, i);
   for (int i = threadIdx.x; i < 1024; i += 64 * W2K) tab[kTwiddleCount + i] = p.tw2k[i];
+  // the synthesis window with the transform's 1/2048 folded in, shared by the block's waves: read from global memory
+  // per frame it was as many bytes through the vector-memory path as the spectrum row itself
+  float4* wintab = reinterpret_cast<float4*>(tab + kTwiddleCount + 1024);
+  for (int i = threadIdx.x; i < 512; i += 64 * W2K) {
+    const float4 w = reinterpret_cast<const float4*>(p.window)[i];
+    const float sc = 1.0f / 2048.0f;
+    wintab[i] = make_float4(w.x * sc, w.y * sc, w.z * sc, w.w * sc);
+  }
   __syncthreads();
   const LdsTwiddles<true> tw = {tab, lane};
   const long long run = (long long)blockIdx.x * W2K + wave;
@@ -455,15 +463,42 @@ __global__ __launch_bounds__(64 * W2K, 2) void istft2048_ola_kernel(P2kOla p) {
   long long c1 = c0 + p.blocks_per_run;
   if (c1 > LEAD + T - 1) c1 = LEAD + T - 1;
   if (c0 >= c1) return;
-  const float4* win4 = reinterpret_cast<const float4*>(p.window);
   const float4* env4 = reinterpret_cast<const float4*>(p.env);
-  const float scale = 1.0f / 2048.0f;
   float4 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   float* yclip = p.y + b * (HOP * (T - 1));
 
+  // Complex input: the next frame's row is requested before the current one is transformed (one frame = 8 KB per wave
+  // in flight; the index is clamped into the clip so that the load is unconditional -- a conditional load would make
+  // the compiler drain vmcnt on the spot).  Until round 3 every frame's loads were issued and consumed back to back.
+  v2f nxt[16];
+  float nxt_nyq = 0.f;
+  auto request = [&](long long t) {
+    const long long tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    const float2* row = p.X + (b * T + tc) * F2K;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) nxt[m] = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(row) + lane + 64 * m);
+    nxt_nyq = reinterpret_cast<const float*>(row + 1024)[0];
+  };
+  if constexpr (!POLAR) request(c0 - (R - 1));
+  // reciprocal of the fully overlapped envelope: one division per wave instead of four per hop (<= 1 ulp from acc / e)
+  float4 rcp_full[HS];
+#pragma unroll
+  for (int j = 0; j < HS; ++j) {
+    const float4 e = env4[(size_t)((1 << R) - 1) * (HOP / 4) + lane + 64 * j];
+    rcp_full[j] = make_float4(1.0f / e.x, 1.0f / e.y, 1.0f / e.z, 1.0f / e.w);
+  }
+
   for (long long t = c0 - (R - 1); t < c1; ++t) {
+    v2f cur[16];
+    float cur_nyq = 0.f;
+    if constexpr (!POLAR) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) cur[m] = nxt[m];
+      cur_nyq = nxt_nyq;
+      request(t + 1);
+    }
     if (t >= 0 && t < T) {
       const long long f = b * T + t;
       v2f v[16];
@@ -482,10 +517,10 @@ __global__ __launch_bounds__(64 * W2K, 2) void istft2048_ola_kernel(P2kOla p) {
         sincos_big2k(prow[1024], sn, cs);
         nyq_re = mrow[1024] * cs;
       } else {
-        const float2* row = p.X + f * F2K;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = to_v(row[lane + 64 * m]);
-        nyq_re = row[1024].x;
+        for (int m = 0; m < 16; ++m) v[m] = cur[m];
+        nyq_re = cur_nyq;
+        (void)f;
       }
       if (lane == 0) v[0].y = 0.0f;
       v2f pm[16];
@@ -507,11 +542,11 @@ __global__ __launch_bounds__(64 * W2K, 2) void istft2048_ola_kernel(P2kOla p) {
       fft512<true>(zo, tw, lds, lane);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float4 w = win4[lane + 64 * j];
-        acc[j].x += ze[j].x * (w.x * scale);
-        acc[j].y += ze[j].y * (w.y * scale);
-        acc[j].z += zo[j].x * (w.z * scale);
-        acc[j].w += zo[j].y * (w.w * scale);
+        const float4 w = wintab[lane + 64 * j];
+        acc[j].x += ze[j].x * w.x;
+        acc[j].y += ze[j].y * w.y;
+        acc[j].z += zo[j].x * w.z;
+        acc[j].w += zo[j].y * w.w;
       }
     }
     // block t is complete: frames t - R + 1 .. t are all that cover it
@@ -523,11 +558,22 @@ __global__ __launch_bounds__(64 * W2K, 2) void istft2048_ola_kernel(P2kOla p) {
         if (ft >= 0 && ft < T) mask |= 1 << q;
       }
       float* dst = yclip + (t - LEAD) * HOP;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      if (mask == (1 << R) - 1) {
+        // a hop's value must not depend on how the launch cut the clip into runs: every fully overlapped hop takes
+        // the reciprocal form, whichever run emits it
 #pragma unroll
-      for (int j = 0; j < HS; ++j) {
-        const float4 e = env4[(size_t)mask * (HOP / 4) + lane + 64 * j];
-        *reinterpret_cast<float4*>(dst + 4 * (lane + 64 * j)) =
-            make_float4(acc[j].x / e.x, acc[j].y / e.y, acc[j].z / e.z, acc[j].w / e.w);
+        for (int j = 0; j < HS; ++j)
+          __builtin_nontemporal_store((v4f){acc[j].x * rcp_full[j].x, acc[j].y * rcp_full[j].y, acc[j].z * rcp_full[j].z,
+                                            acc[j].w * rcp_full[j].w},
+                                      reinterpret_cast<v4f*>(dst + 4 * (lane + 64 * j)));
+      } else {
+#pragma unroll
+        for (int j = 0; j < HS; ++j) {
+          const float4 e = env4[(size_t)mask * (HOP / 4) + lane + 64 * j];
+          *reinterpret_cast<float4*>(dst + 4 * (lane + 64 * j)) =
+              make_float4(acc[j].x / e.x, acc[j].y / e.y, acc[j].z / e.z, acc[j].w / e.w);
+        }
       }
     }
 #pragma unroll
