@@ -493,13 +493,21 @@ struct P4kOla {
 template <bool POLAR, int HS>
 __global__ __launch_bounds__(64 * W4K, 2) void istft4096_ola_kernel(P4kOla p) {
   constexpr int HOP = 512 * HS, R = 8 / HS, LEAD = 2048 / HOP;      // LEAD: blocks trimmed at the front
-  __shared__ float2 lds_all[kLds4k];
+  __shared__ float2 lds_all[kLds4k + 2048];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
   float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
   float2* tab = lds_all + W4K * kFftLdsFloat2PerWave;
   float2* t4 = tab + kTwiddleCount;
   const v2f* w4 = reinterpret_cast<const v2f*>(t4) + lane;
   const v2f* wr = reinterpret_cast<const v2f*>(t4 + 2048) + lane;
+  // the synthesis window with the transform's 1/4096 folded in, shared by the block's waves (16 KB): read from global
+  // memory per frame it was as many bytes through the vector-memory path as the spectrum row itself
+  float4* wintab = reinterpret_cast<float4*>(t4 + kTab4k);
+  for (int i = threadIdx.x; i < 1024; i += 64 * W4K) {
+    const float4 w = reinterpret_cast<const float4*>(p.window)[i];
+    const float sc = 1.0f / 4096.0f;
+    wintab[i] = make_float4(w.x * sc, w.y * sc, w.z * sc, w.w * sc);
+  }
   stage_tables4k<true>(p.tw, p.tw4k, tab, t4);
   const LdsTwiddles<true> tw = {tab, lane};
   const long long run = (long long)blockIdx.x * W4K + wave;
@@ -511,9 +519,16 @@ __global__ __launch_bounds__(64 * W4K, 2) void istft4096_ola_kernel(P4kOla p) {
   long long c1 = c0 + p.blocks_per_run;
   if (c1 > LEAD + T - 1) c1 = LEAD + T - 1;
   if (c0 >= c1) return;
-  const float4* win4 = reinterpret_cast<const float4*>(p.window);
   const float4* env4 = reinterpret_cast<const float4*>(p.env);
-  const float scale = 1.0f / 4096.0f;
+  // reciprocal of the fully overlapped envelope: one division per wave instead of eight per hop (<= 1 ulp from acc / e)
+  float4 rcpa[HS], rcpb[HS];
+#pragma unroll
+  for (int j = 0; j < HS; ++j) {
+    const float4 ea = env4[(size_t)((1 << R) - 1) * (HOP / 4) + 2 * (lane + 64 * j)];
+    const float4 eb = env4[(size_t)((1 << R) - 1) * (HOP / 4) + 2 * (lane + 64 * j) + 1];
+    rcpa[j] = make_float4(1.0f / ea.x, 1.0f / ea.y, 1.0f / ea.z, 1.0f / ea.w);
+    rcpb[j] = make_float4(1.0f / eb.x, 1.0f / eb.y, 1.0f / eb.z, 1.0f / eb.w);
+  }
   float4 acca[8], accb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acca[j] = accb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -529,16 +544,16 @@ __global__ __launch_bounds__(64 * W4K, 2) void istft4096_ola_kernel(P4kOla p) {
       fft512<true>(y3, tw, lds, lane);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float4 wa = win4[2 * (lane + 64 * j)];
-        const float4 wb = win4[2 * (lane + 64 * j) + 1];
-        acca[j].x += y0[j].x * (wa.x * scale);
-        acca[j].y += y0[j].y * (wa.y * scale);
-        acca[j].z += y1[j].x * (wa.z * scale);
-        acca[j].w += y1[j].y * (wa.w * scale);
-        accb[j].x += y2[j].x * (wb.x * scale);
-        accb[j].y += y2[j].y * (wb.y * scale);
-        accb[j].z += y3[j].x * (wb.z * scale);
-        accb[j].w += y3[j].y * (wb.w * scale);
+        const float4 wa = wintab[2 * (lane + 64 * j)];
+        const float4 wb = wintab[2 * (lane + 64 * j) + 1];
+        acca[j].x += y0[j].x * wa.x;
+        acca[j].y += y0[j].y * wa.y;
+        acca[j].z += y1[j].x * wa.z;
+        acca[j].w += y1[j].y * wa.w;
+        accb[j].x += y2[j].x * wb.x;
+        accb[j].y += y2[j].y * wb.y;
+        accb[j].z += y3[j].x * wb.z;
+        accb[j].w += y3[j].y * wb.w;
       }
     }
     // block t is complete: frames t - R + 1 .. t are all that cover it
@@ -550,13 +565,25 @@ __global__ __launch_bounds__(64 * W4K, 2) void istft4096_ola_kernel(P4kOla p) {
         if (ft >= 0 && ft < T) mask |= 1 << q;
       }
       float* dst = yclip + (t - LEAD) * HOP;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      if (mask == (1 << R) - 1) {       // every fully overlapped hop takes the reciprocal form, whichever run emits it
 #pragma unroll
-      for (int j = 0; j < HS; ++j) {
-        const float4 ea = env4[(size_t)mask * (HOP / 4) + 2 * (lane + 64 * j)];
-        const float4 eb = env4[(size_t)mask * (HOP / 4) + 2 * (lane + 64 * j) + 1];
-        float4* d4 = reinterpret_cast<float4*>(dst + 8 * (lane + 64 * j));
-        d4[0] = make_float4(acca[j].x / ea.x, acca[j].y / ea.y, acca[j].z / ea.z, acca[j].w / ea.w);
-        d4[1] = make_float4(accb[j].x / eb.x, accb[j].y / eb.y, accb[j].z / eb.z, accb[j].w / eb.w);
+        for (int j = 0; j < HS; ++j) {
+          v4f* d4 = reinterpret_cast<v4f*>(dst + 8 * (lane + 64 * j));
+          __builtin_nontemporal_store((v4f){acca[j].x * rcpa[j].x, acca[j].y * rcpa[j].y, acca[j].z * rcpa[j].z,
+                                            acca[j].w * rcpa[j].w}, d4);
+          __builtin_nontemporal_store((v4f){accb[j].x * rcpb[j].x, accb[j].y * rcpb[j].y, accb[j].z * rcpb[j].z,
+                                            accb[j].w * rcpb[j].w}, d4 + 1);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < HS; ++j) {
+          const float4 ea = env4[(size_t)mask * (HOP / 4) + 2 * (lane + 64 * j)];
+          const float4 eb = env4[(size_t)mask * (HOP / 4) + 2 * (lane + 64 * j) + 1];
+          float4* d4 = reinterpret_cast<float4*>(dst + 8 * (lane + 64 * j));
+          d4[0] = make_float4(acca[j].x / ea.x, acca[j].y / ea.y, acca[j].z / ea.z, acca[j].w / ea.w);
+          d4[1] = make_float4(accb[j].x / eb.x, accb[j].y / eb.y, accb[j].z / eb.z, accb[j].w / eb.w);
+        }
       }
     }
 #pragma unroll

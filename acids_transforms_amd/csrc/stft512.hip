@@ -541,6 +541,14 @@ __global__ __launch_bounds__(64 * W5) void istft512_ola_kernel(P5Ola p) {
 #pragma unroll
   for (int j = 0; j < HS; ++j) carry[j] = (v2f){0.f, 0.f};
 
+  // reciprocal of the fully overlapped envelope, once per wave: in the steady state a block needs neither the envelope
+  // load nor the division (<= 1 ulp from sum / e); every fully overlapped block takes this form, whichever run emits it
+  float2 rcp_full[HS];
+#pragma unroll
+  for (int j = 0; j < HS; ++j) {
+    const float2 e = env2[(size_t)((1 << R) - 1) * (HOP / 2) + u + 32 * j];
+    rcp_full[j] = make_float2(1.0f / e.x, 1.0f / e.y);
+  }
   constexpr int WARM = (R + 1) / 2;                                       // pairs that start early: R - 1 frames back
   for (long long i = i0 - WARM; i < i1; ++i) {
     // slide this lane's window two hops; what leaves behind the first hop is the carry
@@ -585,8 +593,13 @@ __global__ __launch_bounds__(64 * W5) void istft512_ola_kernel(P5Ola p) {
         // a lane pair holds the same sum: even lanes store the first half of the slot pair range, odd lanes ... both
         // lanes of a pair would write the same 8 bytes, so the even lane alone stores
         if (valid && par == 0) {
-          const float2 e = env2[(size_t)mask * (HOP / 2) + u + 32 * j];
-          dst[u + 32 * j] = make_float2(sum.x / e.x, sum.y / e.y);
+          if (mask == (1 << R) - 1) {
+            __builtin_nontemporal_store((v2f){sum.x * rcp_full[j].x, sum.y * rcp_full[j].y},
+                                        reinterpret_cast<v2f*>(dst + u + 32 * j));
+          } else {
+            const float2 e = env2[(size_t)mask * (HOP / 2) + u + 32 * j];
+            dst[u + 32 * j] = make_float2(sum.x / e.x, sum.y / e.y);
+          }
         }
       }
     }
