@@ -220,7 +220,7 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
 // NT: those stores non-temporal.  tools/ubench/stream_pattern2.hip prices the pattern: rows 4.7 TB/s, aligned blocks
 // 4.95, aligned + nt 5.0-5.3 (profiles/r03a_*).
 template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2, int SP = 0,
-          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false, int HYB = 0>
+          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false, int HYB = 0, int FC = 1, bool FP2 = false>
 __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
   // HYB (with TWLDS): bit 0 -- the two pass twiddle tables in registers, only the merge's W1024 rows from LDS
   // (HybridTwiddles); bit 1 -- the analysis window in registers.  Both trade LDS reads (the busiest unit of these
@@ -452,11 +452,12 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
       wave_lds_sync();
 #pragma unroll
       for (int m = 0; m < 8; ++m)
-        absrow[col + 64 * m] = __builtin_amdgcn_sqrtf(fmaf(v[m].x, v[m].x, v[m].y * v[m].y));
+        absrow[col + 64 * m] = FP2 ? fmaf(v[m].x, v[m].x, v[m].y * v[m].y)
+                                   : __builtin_amdgcn_sqrtf(fmaf(v[m].x, v[m].x, v[m].y * v[m].y));
       // bin 512.  Entries 513 .. 639 are whatever the FFT left in the slab: a walk that runs past its band
       // multiplies them by zero weights (finite leftovers: the frame's own intermediate values; a frame
       // that holds inf / NaN yields NaN features either way)
-      if (col == 0) absrow[512] = fabsf(nyq.x);
+      if (col == 0) absrow[512] = FP2 ? nyq.x * nyq.x : fabsf(nyq.x);
       wave_lds_sync();
       const float4* a0 = reinterpret_cast<const float4*>(absrow + sp_start[0]);
       const float4* a1 = reinterpret_cast<const float4*>(absrow + sp_start[1]);
@@ -482,8 +483,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
         }
       }
       s0 += s2;
-      float f0v = __builtin_amdgcn_logf(1.0f + (s0.x + s0.y)) * 0.69314718055994530942f;
-      float f1v = __builtin_amdgcn_logf(1.0f + (s1.x + s1.y)) * 0.69314718055994530942f;
+      // FC: the contrast as a compile-time constant (1 = log1p, the headline; 2 = log of the clamped value: the log-mel of
+      // BASELINE configs[3]); FP2: |X|^2 instead of |X|
+      float f0v = fwd_contrast(s0.x + s0.y, FC, p.eps);
+      float f1v = fwd_contrast(s1.x + s1.y, FC, p.eps);
       f0v = (f0v - mel_off) * mel_inv;      // no Normalize: offset 0, reciprocal 1 -- the identity, bit for bit
       f1v = (f1v - mel_off) * mel_inv;
       if (sp_f[0] >= 0) frow[sp_f[0]] = f0v;
@@ -1046,6 +1049,7 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   // table and read their twiddles from a workgroup LDS copy, which frees 44 VGPRs for a 4th wave per SIMD to
   // cover the epilogue's LDS round trips (4 % faster than the 3-wave form, A/B on one device).
   int NW = 4;
+  bool fq_logpow = false;
   void (*kernel)(FwdRunParams) = nullptr;
   if (!bank) {
     if (hop == 128)
@@ -1074,6 +1078,12 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
         bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && !getenv("ACIDS_GENERIC_EPILOGUE"))
       kernel = out ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>
                    : stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 2, 8, 2>;
+    // the log-mel of BASELINE configs[3] (log contrast, |X|^2, features only) on the same fixed-length epilogue
+    if (hop == 256 && !polar && !phase && !feat_channel_major && !out && bank->n_passes == 2 && contrast == 2 && power2 &&
+        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && !getenv("ACIDS_GENERIC_EPILOGUE")) {
+      kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 0, false, 2, 2, 8, 2, false, false, 3, 2, true>;
+      fq_logpow = true;
+    }
     if (hop == 128) {
       if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 1>;
       else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true, 0, false, 1> : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 1>;
@@ -1114,6 +1124,7 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
       NW = 4;
       kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 0, false, 2, 2, 8, 2, false, false, 3>;
     }
+    if (fq_logpow) NW = 4;
   }
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
   const long long fpr = plan_units_per_run(B, T, slots, 8, hop == 128 ? 5 : 1);

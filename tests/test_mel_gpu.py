@@ -528,3 +528,36 @@ def test_bf16_magnitude_vs_oracle(dev, contrast):
     assert rel_max(cpu(m.invert(m32(Xd))), cpu(m32.invert(m32(Xd)))) == 0.0
     with pytest.raises(ValueError):
         A.Magnitude(bank_dtype="fp8")
+
+
+@pytest.mark.gpu
+def test_fixed_length_epilogue_forms_match_the_generic_one(dev, monkeypatch):
+    """The fixed-length epilogue of the fused n_fft-1024 forward (round 3: compile-time walk lengths, contrast and
+    power) in its three instantiations -- log1p / |X| with and without the spectrum (the headline), log / |X|^2
+    features only (the log-mel of BASELINE configs[3]) -- against the generic epilogue on the same input and against
+    the oracle; a bank with other walk lengths must still take the generic one."""
+    from acids_transforms_amd import ops
+    g = torch.Generator().manual_seed(4242)
+    x = (torch.randn(5, 30000, generator=g) * 0.2).to(dev)
+    st = A.STFT().to(dev)
+    mag = A.Magnitude(n_mels=128, mode="unipolar", contrast="log1p").to(dev)
+    mag.scale_data(st(x))
+    off, sc = mag._affine()
+    band = mag._banded()
+    assert [int(v) for v in band.pass_len[:2]] == [32, 8]          # what the fixed-length forms are instantiated for
+    cases = [("log1p", 1, True), ("log1p", 1, False), ("log", 2, False)]
+    for contrast, power, want_X in cases:
+        eps = 1e-10 if contrast == "log" else mag._eps
+        args = dict(contrast=contrast, offset=off, scale=sc, eps=eps, power=power, want_spectrum=want_X)
+        Xa, _, fa = ops.stft_mel_forward(x, st.window[:1024], band, **args)
+        monkeypatch.setenv("ACIDS_GENERIC_EPILOGUE", "1")
+        Xb, _, fb = ops.stft_mel_forward(x, st.window[:1024], band, **args)
+        monkeypatch.delenv("ACIDS_GENERIC_EPILOGUE")
+        assert rel_max(cpu(fa), cpu(fb)) < 2e-6, (contrast, power, want_X)
+        if want_X:
+            assert rel_max(cpu(torch.view_as_real(Xa)), cpu(torch.view_as_real(Xb))) < 2e-6
+        Xr = O.stft_forward(x.cpu(), O.hann_window(1024), 1024, 256)
+        fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100))
+        m = Xr.abs() ** power
+        want = O.affine(O.contrast(torch.matmul(m, fwd), contrast, eps), float(off), float(sc))
+        assert rel_max(cpu(fa), want.numpy()) < TOL, (contrast, power, want_X)
