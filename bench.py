@@ -814,8 +814,8 @@ def main():
         for hop in (128, 512):
             st = A.STFT(sr=SR, n_fft=N_FFT, hop_length=hop).to(dev)
             Xh = st(x)
-            f_ms = timed_ms(lambda: st(x), 3, 1)
-            i_ms = timed_ms(lambda: st.invert(Xh), 3, 1)
+            f_ms = timed_ms(lambda: st(x), 12, 12)
+            i_ms = timed_ms(lambda: st.invert(Xh), 12, 12)
             frames = B * Xh.shape[-2]
             res["hop_%d" % hop] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(f_ms, 4),
                                    "inverse_ms": round(i_ms, 4), "frames_per_s_fwd_plus_inv": frames / ((f_ms + i_ms) * 1e-3)}
@@ -829,8 +829,8 @@ def main():
         for n in (512, 2048, 4096):
             st = A.STFT(sr=SR, n_fft=n, hop_length=n // 4).to(dev)
             Xh = st(x)
-            f_ms = timed_ms(lambda: st(x), 3, 1)
-            i_ms = timed_ms(lambda: st.invert(Xh), 3, 1)
+            f_ms = timed_ms(lambda: st(x), 12, 12)
+            i_ms = timed_ms(lambda: st.invert(Xh), 12, 12)
             frames = B * Xh.shape[-2]
             bytes_per_frame = (n // 4) * 4 + (n // 2 + 1) * 8
             res["n_fft_%d" % n] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(f_ms, 4), "inverse_ms": round(i_ms, 4),
@@ -839,11 +839,11 @@ def main():
             del Xh
         # MelSpectrogram at torchaudio's / librosa's usual 2048 / 512 / 128 mels: one kernel, the spectrum is never written
         ms_ = A.MFCC(sr=SR, n_fft=2048, hop_length=512, n_mels=128).to(dev)
-        res["melspectrogram_2048_512_128"] = {"ms": round(timed_ms(lambda: ms_(x), 3, 1), 4)}
+        res["melspectrogram_2048_512_128"] = {"ms": round(timed_ms(lambda: ms_(x), 12, 12), 4)}
         st = A.STFT(sr=SR, n_fft=400, hop_length=160).to(dev)
         Xh = st(x)
-        res["n_fft_400_hop_160"] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(timed_ms(lambda: st(x), 3, 1), 4),
-                                    "inverse_ms": round(timed_ms(lambda: st.invert(Xh), 3, 1), 4)}
+        res["n_fft_400_hop_160"] = {"frames_per_clip": int(Xh.shape[-2]), "forward_ms": round(timed_ms(lambda: st(x), 12, 12), 4),
+                                    "inverse_ms": round(timed_ms(lambda: st.invert(Xh), 12, 12), 4)}
         del Xh
         return res
 
