@@ -601,6 +601,7 @@ struct P2kMel {
   const float* offset;   // Normalize (device scalars) or null
   const float* scale;
   long long L, clip_stride, T, total_frames, frames_per_wave;
+  int win_off_f2;        // where the window table starts in dynamic LDS, in float2 units (16-byte aligned)
   BandBank bank;
   int hop, contrast, power2, channel_major, row_floats, table_floats;
   float eps;
@@ -615,7 +616,9 @@ __device__ __forceinline__ float contrast2k(float v, int mode, float eps) {
   }
 }
 
-template <int CMW>    // 1 / 2: channel-major output of a bank with that many passes (register window); 0: anything else
+// CMW 1 / 2: channel-major output of a bank with that many passes (register window); 0: anything else.  WINLDS: the
+// analysis window staged in LDS (when the bank's tables leave 8 KB of the two-blocks-per-CU budget).
+template <int CMW, bool WINLDS>
 __global__ __launch_bounds__(64 * W2K, 2) void stft2048_mel_kernel(P2kMel p) {
   extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: run bookkeeping on the scalar unit
@@ -634,13 +637,18 @@ __global__ __launch_bounds__(64 * W2K, 2) void stft2048_mel_kernel(P2kMel p) {
     lane_tab[64 * p.bank.n_passes + i] = p.bank.lane_filter[i];
   }
   for (int k = 1024 + lane; k < p.row_floats; k += 64) absrow[k] = 0.0f;     // bin 1024 is rewritten per frame
+  // the analysis window, shared by the block's waves (round 3): read from global memory per frame it was 8 KB per frame
+  // through the vector-memory path, as much as the frame's samples
+  float4* wintab = reinterpret_cast<float4*>(lds_all + (WINLDS ? p.win_off_f2 : 0));
+  if constexpr (WINLDS)
+    for (int i = threadIdx.x; i < 512; i += 64 * W2K) wintab[i] = reinterpret_cast<const float4*>(p.window)[i];
+  const float4* win4 = reinterpret_cast<const float4*>(p.window);
   __syncthreads();
   const LdsTwiddles<false> tw = {tab, lane};
   const long long f_begin = ((long long)blockIdx.x * W2K + wave) * p.frames_per_wave;
   long long f_end = f_begin + p.frames_per_wave;
   if (f_end > p.total_frames) f_end = p.total_frames;
   if (f_begin >= f_end) return;
-  const float4* win4 = reinterpret_cast<const float4*>(p.window);
   const v2f hh = {0.5f, 0.5f};
   float off = 0.f, sc = 1.f;
   if (p.offset) {
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(64 * W2K, 2) void stft2048_mel_kernel(P2kMel p) {
     v2f ze[8], zo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float4 w = win4[lane + 64 * j];
+      const float4 w = WINLDS ? wintab[lane + 64 * j] : win4[lane + 64 * j];
       ze[j] = (v2f){nxt[j].x * w.x, nxt[j].y * w.y};
       zo[j] = (v2f){nxt[j].z * w.z, nxt[j].w * w.w};
     }
@@ -821,18 +829,24 @@ int launch_stft2048_mel(const float* x, long long B, long long L, long long clip
   }
   p.table_floats = table_floats;
   p.row_floats = (F2K + max_walk + 63) / 64 * 64;      // a walk that starts on the last bins runs into zeros
-  const size_t lds = sizeof(float2) * (size_t)(W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024) +
-                     sizeof(float) * ((size_t)W2K * p.row_floats + table_floats) + sizeof(int) * (size_t)2 * 64 * bank->n_passes;
+  size_t lds = sizeof(float2) * (size_t)(W2K * kFftLdsFloat2PerWave + kTwiddleCount + 1024) +
+               sizeof(float) * ((size_t)W2K * p.row_floats + table_floats) + sizeof(int) * (size_t)2 * 64 * bank->n_passes;
   if (lds > 80 * 1024) return -2;                       // two workgroups per CU or not at all
+  lds = (lds + 15) / 16 * 16;
+  const bool winlds = lds + 8192 <= 80 * 1024;          // the analysis window (512 float4) too, when it fits
+  if (winlds) {
+    p.win_off_f2 = (int)(lds / sizeof(float2));
+    lds += 8192;
+  }
   // runs of consecutive frames per wave: long enough for the window and the table staging, short enough to fill the chip
   long long fpw = (nframes + 256LL * 8 * W2K - 1) / (256LL * 8 * W2K);
   if (fpw < 8) fpw = 8;
   p.frames_per_wave = fpw;
   const long long waves = (nframes + fpw - 1) / fpw;
   const unsigned grid = (unsigned)((waves + W2K - 1) / W2K);
-  void (*kernel)(P2kMel) = stft2048_mel_kernel<0>;
-  if (channel_major && bank->n_passes == 1) kernel = stft2048_mel_kernel<1>;
-  else if (channel_major && bank->n_passes == 2) kernel = stft2048_mel_kernel<2>;
+  void (*kernel)(P2kMel) = winlds ? stft2048_mel_kernel<0, true> : stft2048_mel_kernel<0, false>;
+  if (channel_major && bank->n_passes == 1) kernel = winlds ? stft2048_mel_kernel<1, true> : stft2048_mel_kernel<1, false>;
+  else if (channel_major && bank->n_passes == 2) kernel = winlds ? stft2048_mel_kernel<2, true> : stft2048_mel_kernel<2, false>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     (void)hipGetLastError();

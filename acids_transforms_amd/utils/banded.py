@@ -182,7 +182,7 @@ class BandedBank:
         self.fusable2048 = (K == 1025 and self.n_passes <= FUSED_MAX_PASSES and self.lmax <= FUSED_MAX_BAND
                             and weights.size <= FUSED_TABLE_FLOATS
                             and 8 * (4 * 568 + 22 * 64 + 1024) + 4 * (4 * row2k + weights.size) + 8 * 64 * self.n_passes
-                            <= 80 * 1024)
+                            <= 80 * 1024)          # (the window joins them in LDS when another 8 KB fit: launcher)
         self.pass_len = pass_len                              # host array handed to the C ABI
         self.walked_macs = 64 * int(pass_len.sum())           # multiply-adds issued per frame (incl. zeros)
         self._host = (lane_filter, lane_start, weights)
