@@ -499,3 +499,27 @@ def test_sliding_aligned_forward_512_full_batch(dev, monkeypatch):
         for cls, w in ((A.DGT, O.gauss_window(n)), (A.STFT, O.hann_window(n))):
             m = cls(n_fft=n, hop_length=h).to(dev)
             assert rel_max(cpu(m(xs.to(dev))), O.stft_forward(xs, w, n, h).numpy()) < TOL, (Bs, Ls)
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_c_abi_output_that_is_not_512_byte_aligned(dev, n):
+    """The aligned-stream forward kernels need a 512-byte aligned output; torch allocations are, a C-ABI caller's
+    pointer need not be.  An output that starts 8 bytes into a buffer must take the row-store kernels and give the
+    same spectrum (through the C ABI directly, as such a caller would)."""
+    from acids_transforms_amd import _lib
+    from acids_transforms_amd._lib import ptr, stream_ptr, check
+    h = n // 4
+    g = torch.Generator().manual_seed(n + 9)
+    x = (torch.randn(3, 24 * n, generator=g) * 0.1).to(dev)
+    st = A.STFT(n_fft=n, hop_length=h).to(dev)
+    want = st(x)
+    B, T, F = want.shape
+    buf = torch.zeros(B * T * F + 1, dtype=torch.complex64, device=dev)
+    out = buf[1:]                                             # 8 bytes past the allocation's start
+    assert out.data_ptr() % 512 == 8
+    check(_lib.lib().at_stft_forward(ptr(x), B, x.shape[1], x.shape[1], T, n, h, 1, ptr(st.window[:n].contiguous()),
+                                     ptr(out), None, stream_ptr()), "at_stft_forward")
+    torch.cuda.synchronize()
+    got = out.reshape(B, T, F)
+    assert rel_max(cpu(torch.view_as_real(got)), cpu(torch.view_as_real(want))) < 2e-6
+    assert complex(buf[0]) == 0j                              # nothing written in front of the output
