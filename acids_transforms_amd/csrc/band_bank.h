@@ -28,4 +28,50 @@ struct PolarOut {
 constexpr int kMaxBandFloats = 8192;   // fused epilogue: LDS copy of the weights (dynamic LDS), 64 * sum(pass_len) floats <= 32 KB
 constexpr int kMaxFusedPasses = 16;    // fused epilogue: passes (the stand-alone projection sizes itself by the LDS budget)
 
+// The fixed-length walk of a two-pass bank (pass lengths FQ0 >= FQ1 quads, compile-time): this lane's two band sums
+// from an LDS row of magnitudes.  Shared by the fused n_fft-1024 epilogue (stft1024.hip) and the stand-alone
+// fixed-form projection (mel_banded.hip) so that the two give the same bits for the same spectrum.  The long pass runs
+// on two independent packed sums (even / odd quads), joined at the end.
+typedef float bb_v2f __attribute__((ext_vector_type(2)));
+template <int FQ0, int FQ1>
+__device__ __forceinline__ void band_walk_fixed(const float* absrow, int start0, int start1, const float* wlds, int lane,
+                                                float& sum0, float& sum1) {
+  const float4* a0 = reinterpret_cast<const float4*>(absrow + start0);
+  const float4* a1 = reinterpret_cast<const float4*>(absrow + start1);
+  const float4* w0 = reinterpret_cast<const float4*>(wlds) + lane;
+  const float4* w1 = w0 + FQ0 * 64;
+  bb_v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < FQ1; ++j) {
+    const float4 av = a1[j], wv = w1[j * 64];
+    s1 = __builtin_elementwise_fma((bb_v2f){av.x, av.y}, (bb_v2f){wv.x, wv.y}, s1);
+    s1 = __builtin_elementwise_fma((bb_v2f){av.z, av.w}, (bb_v2f){wv.z, wv.w}, s1);
+  }
+#pragma unroll
+  for (int j = 0; j < FQ0; ++j) {
+    const float4 av = a0[j], wv = w0[j * 64];
+    if (j & 1) {
+      s2 = __builtin_elementwise_fma((bb_v2f){av.x, av.y}, (bb_v2f){wv.x, wv.y}, s2);
+      s2 = __builtin_elementwise_fma((bb_v2f){av.z, av.w}, (bb_v2f){wv.z, wv.w}, s2);
+    } else {
+      s0 = __builtin_elementwise_fma((bb_v2f){av.x, av.y}, (bb_v2f){wv.x, wv.y}, s0);
+      s0 = __builtin_elementwise_fma((bb_v2f){av.z, av.w}, (bb_v2f){wv.z, wv.w}, s0);
+    }
+  }
+  s0 += s2;
+  sum0 = s0.x + s0.y;
+  sum1 = s1.x + s1.y;
+}
+
+// Contrast of the fused / fixed-form epilogues.  The arguments are >= eps = 1.19e-7 (never denormal), so the hardware
+// log2 (1 ulp) times ln 2 / log10 2 is within ~2 ulp of logf / log10f at a sixth of the instructions.
+__device__ __forceinline__ float band_contrast_fast(float v, int mode, float eps) {
+  switch (mode) {
+    case 1: return __builtin_amdgcn_logf(1.0f + v) * 0.69314718055994530942f;
+    case 2: return __builtin_amdgcn_logf(fmaxf(v, eps)) * 0.69314718055994530942f;
+    case 3: return __builtin_amdgcn_logf(fmaxf(v, eps)) * 0.30102999566398119521f;
+    default: return v;
+  }
+}
+
 }  // namespace at_hip

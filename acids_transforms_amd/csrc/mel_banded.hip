@@ -18,6 +18,7 @@
 
 #include "../../include/acids_hip.h"
 #include "band_bank.h"
+#include <stdlib.h>
 #include "mel_gemm.h"   // A_* / C_* codes
 
 namespace at_hip {
@@ -318,6 +319,119 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Fixed form of the headline projection (round 3): complex rows of 513 bins -> normalise(log1p(|X| @ bank)) for a
+// two-pass bank whose walks are FQ0 and FQ1 quads long (128 mel filters at 44.1 kHz: 8 and 2), row-major output.
+// Everything the general kernel above decides at run time (input kind, contrast, direction, phase side outputs,
+// layout, pass count and lengths) is fixed here, and the arithmetic is the fused n_fft-1024 epilogue's own
+// (band_walk_fixed, hardware log2, reciprocal of the scale): `Magnitude.forward` on a stored spectrum and the fused
+// `STFT + Magnitude` kernel give the same bits.  One wave per row, rows requested one ahead (two register sets swapping
+// roles), eight waves per block sharing the 10 KB weight table.
+// ---------------------------------------------------------------------------
+struct FixedProjParams {
+  const float2* X;       // rows x 513 complex64, contiguous
+  float* out;            // rows x N
+  const float* offset;   // device scalars or null
+  const float* scale;
+  const float* weights;  // band table, 64 * 4 * (FQ0 + FQ1) floats
+  const int* lane_start; // [2][64]
+  const int* lane_filter;
+  long long rows, rows_per_wave;
+  int N;
+};
+
+template <int FQ0, int FQ1>
+__global__ __launch_bounds__(64 * kBandedWaves, 4) void mel_fixed_kernel(FixedProjParams p) {
+  constexpr int kTable = 64 * 4 * (FQ0 + FQ1);
+  constexpr int kRow = 640;                       // 513 bins + what a walk may run past (zero weights there)
+  __shared__ __attribute__((aligned(16))) float wlds[kTable];
+  __shared__ __attribute__((aligned(16))) float rows_lds[kBandedWaves][kRow];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < kTable; i += 64 * kBandedWaves) wlds[i] = p.weights[i];
+  float* absrow = rows_lds[wave];
+  absrow[576 + lane] = 0.0f;                      // 513 .. 575 are rewritten per row (zeros), 576 .. 639 stay zero
+  __syncthreads();
+  const int start0 = p.lane_start[lane], start1 = p.lane_start[64 + lane];
+  const int f0 = p.lane_filter[lane], f1 = p.lane_filter[64 + lane];
+  float off = 0.f, inv = 1.f;
+  if (p.offset) {
+    off = *p.offset;
+    inv = 1.0f / *p.scale;
+  }
+  const long long w_id = (long long)blockIdx.x * kBandedWaves + wave;
+  long long r = w_id * p.rows_per_wave;
+  long long r_end = r + p.rows_per_wave;
+  if (r_end > p.rows) r_end = p.rows;
+  if (r >= r_end) return;
+  typedef float v2f_ __attribute__((ext_vector_type(2)));
+  auto fetch = [&](long long row, v2f_ (&v)[8], float& ny) {
+    const v2f_* src = reinterpret_cast<const v2f_*>(p.X + row * 513);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = src[lane + 64 * m];
+    ny = reinterpret_cast<const float*>(src + 512)[0];      // broadcast: only the real part of the (real) Nyquist bin
+  };
+  auto walk = [&](long long row, const v2f_ (&v)[8], float ny) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) absrow[lane + 64 * m] = __builtin_amdgcn_sqrtf(fmaf(v[m].x, v[m].x, v[m].y * v[m].y));
+    absrow[512 + lane] = (lane == 0) ? fabsf(ny) : 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float s0, s1;
+    band_walk_fixed<FQ0, FQ1>(absrow, start0, start1, wlds, lane, s0, s1);
+    const float y0 = (band_contrast_fast(s0, 1, 0.f) - off) * inv;
+    const float y1 = (band_contrast_fast(s1, 1, 0.f) - off) * inv;
+    float* orow = p.out + row * p.N;
+    if (f0 >= 0) orow[f0] = y0;
+    if (f1 >= 0) orow[f1] = y1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // two rows requested ahead of the one being walked (three register sets with rotating roles: 8 KB per wave in
+  // flight; a request past the run's end re-reads its last row)
+  v2f_ ra[8], rb[8], rc[8];
+  float na, nb, nc;
+  const long long last = r_end - 1;
+  fetch(r, ra, na);
+  fetch(r + 1 < r_end ? r + 1 : last, rb, nb);
+  while (r < r_end) {
+    fetch(r + 2 < r_end ? r + 2 : last, rc, nc);
+    walk(r, ra, na);
+    if (++r >= r_end) break;
+    fetch(r + 2 < r_end ? r + 2 : last, ra, na);
+    walk(r, rb, nb);
+    if (++r >= r_end) break;
+    fetch(r + 2 < r_end ? r + 2 : last, rb, nb);
+    walk(r, rc, nc);
+    ++r;
+  }
+}
+
+static int launch_fixed_proj(const BandedParams& b, hipStream_t s) {
+  FixedProjParams p = {};
+  p.X = reinterpret_cast<const float2*>(b.A); p.out = b.out; p.offset = b.offset; p.scale = b.scale;
+  p.weights = b.bank.weights; p.lane_start = b.bank.lane_start; p.lane_filter = b.bank.lane_filter;
+  p.rows = b.rows; p.N = b.bank.n_filters;
+  static thread_local long long slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 256, nb = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mel_fixed_kernel<8, 2>, 64 * kBandedWaves, 0) != hipSuccess || nb <= 0) nb = 1;
+    slots = (long long)cus * nb * kBandedWaves;
+  }
+  long long rpw = (p.rows + 4 * slots - 1) / (4 * slots);
+  if (rpw < 8) rpw = 8;
+  p.rows_per_wave = rpw;
+  const long long waves = (p.rows + rpw - 1) / rpw;
+  hipLaunchKernelGGL((mel_fixed_kernel<8, 2>), dim3((unsigned)((waves + kBandedWaves - 1) / kBandedWaves)), dim3(64 * kBandedWaves), 0, s, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+}
+
 template <bool CPLX>
 static int launch_banded(const BandedParams& p0, size_t dyn_lds, hipStream_t s) {
   BandedParams p = p0;
@@ -435,6 +549,11 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
   p.table_floats = (int)table_floats;
   const size_t dyn_lds = table_floats * sizeof(float) + (size_t)2 * 64 * n_passes * sizeof(int);
   hipStream_t s = (hipStream_t)stream;
+  // the headline projection in its fixed form: |X| of 513-bin rows, log1p, two passes of 8 and 2 quads, row-major
+  if (a_kind == A_COMPLEX_ABS && !inverse && contrast == C_LOG1P && K == 513 && lda == 513 && ld_out == n_filters &&
+      T_transposed == 0 && !phase_out && !phase_in && n_passes == 2 && pass_len_host[0] == 32 && pass_len_host[1] == 8 &&
+      (((uintptr_t)A) & 7) == 0 && !getenv("ACIDS_GENERIC_EPILOGUE"))
+    return launch_fixed_proj(p, s);
   return a_kind >= A_REAL ? launch_banded<false>(p, dyn_lds, s) : launch_banded<true>(p, dyn_lds, s);
 }
 

@@ -182,14 +182,7 @@ __device__ __forceinline__ float2 load_pair(const float* clip, long long L, long
 
 // Contrast of the fused epilogue.  The arguments are >= eps = 1.19e-7 (never denormal), so the hardware log2
 // (1 ulp) times ln 2 / log10 2 is within ~2 ulp of logf / log10f at a sixth of the instructions.
-__device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) {
-  switch (mode) {
-    case 1: return __builtin_amdgcn_logf(1.0f + v) * 0.69314718055994530942f;
-    case 2: return __builtin_amdgcn_logf(fmaxf(v, eps)) * 0.69314718055994530942f;
-    case 3: return __builtin_amdgcn_logf(fmaxf(v, eps)) * 0.30102999566398119521f;
-    default: return v;
-  }
-}
+__device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) { return band_contrast_fast(v, mode, eps); }
 
 // MEL: 0 = spectrum only; 1 = spectrum + fused banded-filterbank features; 2 = features only.
 // FWD_WAVES waves per workgroup share the LDS constant tables (twiddles are always staged there; TWLDS makes
@@ -459,34 +452,12 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
       // that holds inf / NaN yields NaN features either way)
       if (col == 0) absrow[512] = FP2 ? nyq.x * nyq.x : fabsf(nyq.x);
       wave_lds_sync();
-      const float4* a0 = reinterpret_cast<const float4*>(absrow + sp_start[0]);
-      const float4* a1 = reinterpret_cast<const float4*>(absrow + sp_start[1]);
-      const float4* w0 = reinterpret_cast<const float4*>(wlds) + lane;
-      const float4* w1 = w0 + FQ0 * 64;
-      v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < FQ1; ++j) {
-        const float4 av = a1[j], wv = w1[j * 64];
-        s1 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, s1);
-        s1 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, s1);
-      }
-      // the long pass on two independent sums (even / odd quads): half the dependent-latency chain
-#pragma unroll
-      for (int j = 0; j < FQ0; ++j) {
-        const float4 av = a0[j], wv = w0[j * 64];
-        if (j & 1) {
-          s2 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, s2);
-          s2 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, s2);
-        } else {
-          s0 = __builtin_elementwise_fma((v2f){av.x, av.y}, (v2f){wv.x, wv.y}, s0);
-          s0 = __builtin_elementwise_fma((v2f){av.z, av.w}, (v2f){wv.z, wv.w}, s0);
-        }
-      }
-      s0 += s2;
+      float sum0, sum1;
+      band_walk_fixed<FQ0, FQ1>(absrow, sp_start[0], sp_start[1], wlds, lane, sum0, sum1);
       // FC: the contrast as a compile-time constant (1 = log1p, the headline; 2 = log of the clamped value: the log-mel of
       // BASELINE configs[3]); FP2: |X|^2 instead of |X|
-      float f0v = fwd_contrast(s0.x + s0.y, FC, p.eps);
-      float f1v = fwd_contrast(s1.x + s1.y, FC, p.eps);
+      float f0v = band_contrast_fast(sum0, FC, p.eps);
+      float f1v = band_contrast_fast(sum1, FC, p.eps);
       f0v = (f0v - mel_off) * mel_inv;      // no Normalize: offset 0, reciprocal 1 -- the identity, bit for bit
       f1v = (f1v - mel_off) * mel_inv;
       if (sp_f[0] >= 0) frow[sp_f[0]] = f0v;

@@ -561,3 +561,36 @@ def test_fixed_length_epilogue_forms_match_the_generic_one(dev, monkeypatch):
         m = Xr.abs() ** power
         want = O.affine(O.contrast(torch.matmul(m, fwd), contrast, eps), float(off), float(sc))
         assert rel_max(cpu(fa), want.numpy()) < TOL, (contrast, power, want_X)
+
+
+@pytest.mark.gpu
+def test_fixed_form_projection_equals_the_fused_epilogue_bit_for_bit(dev, monkeypatch):
+    """`Magnitude.forward` on a stored spectrum (the fixed-form stand-alone projection, round 3) and the fused
+    `STFT + Magnitude` kernel share their arithmetic: for the headline bank the two feature tensors are the SAME bits
+    (ADVICE r2 had found them 1.5 ulp apart); both are within 1e-5 of the oracle, and the general projection kernel
+    (ACIDS_GENERIC_EPILOGUE=1) agrees to 2e-6."""
+    g = torch.Generator().manual_seed(777)
+    x = (torch.randn(7, 40000, generator=g) * 0.2).to(dev)
+    st = A.STFT().to(dev)
+    mag = A.Magnitude(n_mels=128, mode="unipolar", contrast="log1p").to(dev)
+    X = st(x)
+    mag.scale_data(X)
+    Xf, fused = mag.forward_fused(st, x, return_spectrum=True)
+    assert torch.equal(torch.view_as_real(Xf), torch.view_as_real(X))
+    alone = mag(X)
+    assert torch.equal(alone, fused)
+    monkeypatch.setenv("ACIDS_GENERIC_EPILOGUE", "1")
+    general = mag(X)
+    monkeypatch.delenv("ACIDS_GENERIC_EPILOGUE")
+    assert rel_max(cpu(alone), cpu(general)) < 2e-6
+    Xr = O.stft_forward(x.cpu(), O.hann_window(1024), 1024, 256)
+    fwd, _ = O.magnitude_banks(O.melscale_fbanks(513, 0.0, 22050.0, 128, 44100))
+    want = O.magnitude_forward(Xr, fwd, "log1p", float(mag.norm.offset), float(mag.norm.scale))
+    assert rel_max(cpu(alone), want.numpy()) < TOL
+    # rows that are not a multiple of anything, a single row
+    for rows in (1, 5, 1027):
+        Xs = X.reshape(-1, 513)[:rows].contiguous()
+        monkeypatch.setenv("ACIDS_GENERIC_EPILOGUE", "1")
+        ref = mag(Xs)
+        monkeypatch.delenv("ACIDS_GENERIC_EPILOGUE")
+        assert rel_max(cpu(mag(Xs)), cpu(ref)) < 2e-6, rows
