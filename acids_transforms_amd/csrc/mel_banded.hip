@@ -18,7 +18,9 @@
 
 #include "../../include/acids_hip.h"
 #include "band_bank.h"
+#include "run_plan.h"
 #include <stdlib.h>
+#include <string.h>
 #include "mel_gemm.h"   // A_* / C_* codes
 
 namespace at_hip {
@@ -670,6 +672,163 @@ __global__ __launch_bounds__(256) void small_proj_kernel(SmallProjParams p) {
   }
 }
 
+// The same contraction on the matrix cores, for K = 128 / 80 / 64 and 16-byte aligned rows (MFCC: 128 log-mel values ->
+// 40 coefficients, 706 560 rows).  The kernel above is bound by its LDS broadcasts (32 ds_read_b128 per row per wave:
+// 0.343 ms against 0.09 ms of HBM traffic); here the rows never pass through LDS.  out^T = W^T x^T in tiles of
+// 16 channels x 16 rows with v_mfma_f32_16x16x4_f32 (fp32 products, fp32 accumulation -- no reduced precision): the A
+// operand is W^T (lane (m, g) supplies W[k][16 mt + m] for its K/4 values of k), the B operand is x^T -- lane (m, g)
+// supplies x[row m][k] for the same k, which it loads itself from global memory.  The contraction order is free, so step
+// (j, c) takes k = 16 j + 4 g + c: a lane's operands are the float4s at k = 16 j + 4 g, four lanes cover 64 contiguous
+// bytes of a row and every byte of the tile is requested exactly once.  MT = ceil(N / 16) channel tiles (40 -> 3: 17 %
+// of the MFMA work is padding), KS = K / 16.  0.133 ms (A/Bs in profiles/r03h_small_projection.md); the floor of the
+// MFMA pipe is 0.055 ms at 2.4 GHz, of the memory system 0.09 ms.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+// WLDS: the A operands are read from LDS (one ds_read_b128 per (mt, j): 24 KB per tile and wave, a sixth of what the
+// LDS delivers in the tile's MFMA time) instead of being held in 32 MT KS / 8 registers: four waves per SIMD instead of two.
+template <int KS, int MT, bool WLDS, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WLDS ? 4 : 2))) void small_proj_mfma_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                              SmallProjParams p) {
+  __shared__ v4f_t wlds[WLDS ? MT * KS * 64 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  float w[WLDS ? 1 : MT][WLDS ? 1 : KS][4];
+  if (WLDS) {
+    // wave w fills the (mt, j) slots w, w+4, ..: every lane writes its own operands
+    for (int q = wave; q < MT * KS; q += 4) {
+      const int mt = q / KS, j = q - mt * KS;
+      const int ch = 16 * mt + m;
+      v4f_t v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = ch < p.N ? p.W[(long long)(16 * j + 4 * g + c) * p.N + ch] : 0.0f;
+      wlds[q * 64 + lane] = v;
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < (WLDS ? 1 : MT); ++mt)
+#pragma unroll
+      for (int j = 0; j < (WLDS ? 1 : KS); ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ch = 16 * mt + m, k = 16 * j + 4 * g + c;
+          w[mt][j][c] = ch < p.N ? p.W[(long long)k * p.N + ch] : 0.0f;
+        }
+  }
+  float off = 0.f, sc = 1.f;
+  if (p.offset) {
+    off = *p.offset;
+    sc = *p.scale;
+  }
+  long long r = ((long long)blockIdx.x * 4 + wave) * p.rows_per_wave;      // rows_per_wave is a multiple of 32
+  long long r_end = r + p.rows_per_wave;
+  if (r_end > p.rows) r_end = p.rows;
+  if (r >= r_end) return;
+  const long long last_row = r_end - 1;
+  const int K = 16 * KS;
+  // loads are unconditional: tile rows past the end re-read the last row and are not stored
+  auto fetch = [&](long long r0, float4 (&v)[KS]) {
+    const long long row = r0 + m < last_row ? r0 + m : last_row;
+    const float4* src = reinterpret_cast<const float4*>(x + row * K) + g;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) v[j] = src[4 * j];
+  };
+  auto contract = [&](const float4 (&v)[KS], v4f_t (&acc)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      if (WLDS) {
+        // volatile: the table does not change, and a plain read is hoisted out of the row loop into MT KS x 4 registers
+        typedef const volatile __attribute__((address_space(3))) v4f_t* lds_ptr;
+        v4f_t wq[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wq[mt] = *(lds_ptr)(&wlds[(mt * KS + j) * 64 + lane]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[mt][c], xs[c], acc[mt], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[WLDS ? 0 : mt][WLDS ? 0 : j][c], xs[c], acc[mt], 0, 0, 0);
+      }
+    }
+  };
+  // Two tiles are stored together.  A tile's result has 16 rows on the lanes of each 16-lane group and the group's four
+  // channels in the registers: stored as it is, a channel receives 64 contiguous bytes.  v_permlane16_swap exchanges the
+  // odd groups of the first tile's register with the even groups of the second tile's: afterwards lanes 0..31 (32..63)
+  // hold ONE channel of 32 consecutive rows -- 128 contiguous bytes per channel and store.
+  const int rr = lane & 31, hi = lane >> 5;
+  long long cb = 0, ct = 0;                 // (clip, frame) of the row this lane stores
+  if (p.T > 0) {
+    cb = (r + rr) / p.T;
+    ct = (r + rr) - cb * p.T;
+  }
+  auto store_pair = [&](const v4f_t (&a0)[MT], const v4f_t (&a1)[MT]) {
+    const bool row_ok = r + rr <= last_row;
+    float* base = p.T > 0 ? out + cb * p.N * p.T + ct : out + (r + rr) * p.N;
+    const long long ch_stride = p.T > 0 ? p.T : 1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a0[mt][i]), __float_as_uint(a1[mt][i]), false, false);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ch = 16 * mt + 8 * hi + 4 * h + i;
+          float a = __uint_as_float(sw[h]);
+          if (p.offset) a = (a - off) / sc;
+#ifdef AT_DCT_NOSTORE
+          if (row_ok && ch < p.N && a == 12345.678f) {
+#else
+          if (row_ok && ch < p.N) {
+#endif
+            float* dst = base + ch * ch_stride;
+            if (NT) __builtin_nontemporal_store(a, dst);
+            else *dst = a;
+          }
+        }
+      }
+    r += 32;
+    if (p.T > 0) {
+      ct += 32;
+      while (ct >= p.T) {
+        ct -= p.T;
+        ++cb;
+      }
+    }
+  };
+  float4 va[KS], vb[KS];
+  v4f_t acc0[MT], acc1[MT];
+  fetch(r, va);
+  while (true) {
+    fetch(r + 16, vb);
+    contract(va, acc0);
+    fetch(r + 32, va);
+    contract(vb, acc1);
+    store_pair(acc0, acc1);
+    if (r >= r_end) break;
+  }
+}
+
+template <int KS, bool WLDS, bool NT>
+static bool launch_small_mfma(const SmallProjParams& p, int mt, dim3 grid, hipStream_t s) {
+  const dim3 block(256);
+  switch (mt) {
+    case 1: hipLaunchKernelGGL((small_proj_mfma_kernel<KS, 1, WLDS, NT>), grid, block, 0, s, p.x, p.out, p); return true;
+    case 2: hipLaunchKernelGGL((small_proj_mfma_kernel<KS, 2, WLDS, NT>), grid, block, 0, s, p.x, p.out, p); return true;
+    case 3: hipLaunchKernelGGL((small_proj_mfma_kernel<KS, 3, WLDS, NT>), grid, block, 0, s, p.x, p.out, p); return true;
+    case 4: hipLaunchKernelGGL((small_proj_mfma_kernel<KS, 4, WLDS, NT>), grid, block, 0, s, p.x, p.out, p); return true;
+  }
+  return false;
+}
+
 }  // namespace at_hip
 
 extern "C" int at_project_small(const float* x, int64_t rows, int K, const float* W, int N, const float* offset,
@@ -681,13 +840,35 @@ extern "C" int at_project_small(const float* x, int64_t rows, int K, const float
   if ((offset == nullptr) != (scale == nullptr)) return AT_EINVAL;
   if (K > 128 || N > 64) return AT_EUNSUPPORTED;
   SmallProjParams p = {x, W, out, offset, scale, rows, T_transposed, 0, K, N};
+  hipStream_t s = (hipStream_t)stream;
+  if ((K == 128 || K == 80 || K == 64) && (((uintptr_t)x) & 15) == 0 && !getenv("ACIDS_PROJECT_SMALL_VALU")) {
+    // matrix-core form: every wave a whole number of 32-row tile pairs
+    const char* form = getenv("ACIDS_PROJECT_SMALL_FORM");      // dev switch: "regs", "regs_nt", "lds", "lds_nt"
+    const int f = !form ? 2 : !strcmp(form, "regs") ? 0 : !strcmp(form, "regs_nt") ? 1 : !strcmp(form, "lds") ? 2 : 3;
+    const long long waves_target = (long long)num_cus() * (f >= 2 ? 16 : 8);
+    long long rpw = (rows + waves_target - 1) / waves_target;
+    rpw = (rpw + 31) / 32 * 32;
+    if (rpw < 64) rpw = 64;
+    p.rows_per_wave = rpw;
+    const long long waves = (rows + rpw - 1) / rpw;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    const int mt = (N + 15) / 16;
+    bool ok;
+    if (K == 128 && f == 0) ok = launch_small_mfma<8, false, false>(p, mt, grid, s);
+    else if (K == 128 && f == 1) ok = launch_small_mfma<8, false, true>(p, mt, grid, s);
+    else if (K == 128 && f == 2) ok = launch_small_mfma<8, true, false>(p, mt, grid, s);
+    else if (K == 128) ok = launch_small_mfma<8, true, true>(p, mt, grid, s);
+    else if (K == 80) ok = launch_small_mfma<5, true, true>(p, mt, grid, s);
+    else ok = launch_small_mfma<4, true, true>(p, mt, grid, s);
+    if (!ok) return AT_EINVAL;
+    return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+  }
   const long long waves_target = 256LL * 32;
   long long rpw = (rows + waves_target - 1) / waves_target;
   if (rpw < 4) rpw = 4;
   p.rows_per_wave = rpw;
   const long long waves = (rows + rpw - 1) / rpw;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  hipStream_t s = (hipStream_t)stream;
   const int kq = (K + 3) / 4;
   if (kq <= 8) hipLaunchKernelGGL(small_proj_kernel<8>, grid, block, 0, s, p);
   else if (kq <= 16) hipLaunchKernelGGL(small_proj_kernel<16>, grid, block, 0, s, p);

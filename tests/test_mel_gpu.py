@@ -2,6 +2,7 @@
 fp32 tolerance 1e-5 normwise (north_star); the projection runs on exact-fp32 MFMA."""
 import numpy as np
 import pytest
+import os
 import torch
 
 import acids_transforms_amd as A
@@ -376,7 +377,11 @@ def test_small_projection_shapes(dev):
     gen = torch.Generator().manual_seed(51)
     off = torch.tensor(0.25, device=dev)
     sc = torch.tensor(3.0, device=dev)
-    for (B, T, K, N) in [(3, 17, 128, 40), (1, 1, 128, 40), (5, 8, 64, 13), (2, 23, 20, 64), (7, 3, 128, 1), (2, 1000, 33, 7)]:
+    # K = 128 / 80 / 64 take the matrix-core form (tile pairs of 32 rows: row counts around 32 and 64, clips shorter
+    # than a tile, every count of 16-channel tiles), the other K the one-wave-per-row form
+    for (B, T, K, N) in [(3, 17, 128, 40), (1, 1, 128, 40), (5, 8, 64, 13), (2, 23, 20, 64), (7, 3, 128, 1), (2, 1000, 33, 7),
+                         (3, 17, 80, 20), (2, 690, 128, 40), (9, 7, 128, 64), (1, 100, 64, 17), (4, 33, 80, 40),
+                         (1, 31, 128, 33), (1, 32, 128, 16), (1, 65, 128, 48), (64, 1, 128, 40)]:
         x = torch.randn(B, T, K, generator=gen)
         W = torch.randn(K, N, generator=gen)
         want = (x.double() @ W.double()).float()
@@ -386,6 +391,16 @@ def test_small_projection_shapes(dev):
             assert y.shape == (B, T, N) and rel_max(cpu(y), ref.numpy()) < TOL, (B, T, K, N)
             yc = ops.mel_forward_real(x.to(dev), W.to(dev), o, s_, channel_major_T=T)
             assert yc.shape == (B, N, T) and rel_max(cpu(yc), ref.transpose(-2, -1).numpy()) < TOL, (B, T, K, N)
+    # both forms of the same shape agree to rounding (different summation orders)
+    x = torch.randn(6, 50, 128, generator=gen).to(dev)
+    W = torch.randn(128, 40, generator=gen).to(dev)
+    y_mfma = ops.mel_forward_real(x, W, off, sc, channel_major_T=50)
+    os.environ["ACIDS_PROJECT_SMALL_VALU"] = "1"
+    try:
+        y_valu = ops.mel_forward_real(x, W, off, sc, channel_major_T=50)
+    finally:
+        del os.environ["ACIDS_PROJECT_SMALL_VALU"]
+    assert rel_max(cpu(y_mfma), cpu(y_valu)) < 1e-5
     big = torch.randn(4, 10, 200, generator=gen)           # K > 128: the MFMA contraction takes over
     Wb = torch.randn(200, 30, generator=gen)
     assert rel_max(cpu(ops.mel_forward_real(big.to(dev), Wb.to(dev))), (big @ Wb).numpy()) < 1e-4

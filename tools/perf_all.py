@@ -92,6 +92,15 @@ if "phase" in which:
 if "mfcc40" in which:
     mf40 = A.MFCC(n_mfcc=40).to(dev)
     report("MFCC(n_mfcc=40)", timeit(lambda: mf40(x)), 1024 + 4 * 40)
+if "dct40" in which:      # the DCT behind MFCC(n_mfcc=40): 128 log-mel values -> 40 coefficients, channel-major
+    from acids_transforms_amd import ops
+    lm = torch.randn(B, T, 128, device=dev)
+    dct = torch.randn(128, 40, device=dev)
+    report("DCT 128->40", timeit(lambda: ops.mel_forward_real(lm, dct, None, None, channel_major_T=T)), 4 * 128 + 4 * 40)
+    got = ops.mel_forward_real(lm[:4], dct, None, None, channel_major_T=T)
+    want = (lm[:4].double() @ dct.double()).transpose(-1, -2)
+    print("    max |err| vs float64: %.3g (|out| max %.3g)" % ((got.double() - want).abs().max().item(), want.abs().max().item()))
+    del lm
 if "polarfwd" in which:
     from acids_transforms_amd import ops
     pol = A.Polar().to(dev)
