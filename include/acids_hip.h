@@ -300,8 +300,10 @@ int at_mel_project_banded(const void *A, int a_kind, int64_t rows, int64_t lda, 
                           float *phase_out, int64_t ld_phase, const float *phase_offset, const float *phase_scale,
                           const float *phase_in, void *stream);
 
-/* normalise(x @ W) for a small real matrix (K <= 128, N <= 64): the DCT-II behind MFCC(n_mfcc); one wavefront
- * per row with W's columns in registers.  out: (rows, N), or channel-major (rows/T, N, T) when T_transposed > 0. */
+/* normalise(x @ W) for a small real matrix (K <= 128, N <= 64): the DCT-II behind MFCC(n_mfcc).  K = 128 / 80 / 64 with
+ * a 16-byte aligned x: fp32 MFMA tiles (v_mfma_f32_16x16x4_f32, fp32 accumulate); otherwise one wavefront per row with
+ * W's columns in registers.  out: (rows, N), or channel-major (rows/T, N, T) when T_transposed > 0; x and out must not
+ * overlap. */
 int at_project_small(const float *x, int64_t rows, int K, const float *W, int N, const float *offset,
                      const float *scale, float *out, int64_t T_transposed, void *stream);
 

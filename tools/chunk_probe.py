@@ -1,39 +1,40 @@
-#!/usr/bin/env python3
-"""Does running forward and inverse on sub-batches keep the spectrum in the 256 MB Infinity Cache?
-Times the bench step (fused STFT+mel forward, ISTFT inverse) on 1024 clips as one pair of launches and as
-pairs of launches over sub-batches of C clips (a 64-clip spectrum is 181 MB)."""
+"""Does the spectrum survive in the 256 MB infinity cache between the forward and the inverse kernel when the batch is
+walked in sub-batches?  Step of bench.py (fused STFT + Magnitude, then ISTFT) over 1024 clips x 4 s, in chunks of c clips."""
 import os
 import sys
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import acids_transforms_amd as A  # noqa: E402
+import torch
+import acids_transforms_amd as A
 
-dev = torch.device("cuda")
 B, L = 1024, 176400
+dev = torch.device("cuda:0")
 x = torch.randn(B, L, device=dev) * 0.1
-stft = A.STFT(sr=44100, n_fft=1024, hop_length=256).to(dev)
-mag = A.Magnitude(sr=44100, n_fft=1024, n_mels=128, mode="unipolar", contrast="log1p").to(dev)
-mag.scale_data(stft(x[:8]))
+stft = A.STFT().to(dev)
+mag = A.Magnitude(n_mels=128, mode="unipolar", contrast="log1p").to(dev)
+X0 = stft(x[:8])
+mag.scale_data(X0)
+del X0
+chunks = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1024,256,128,64,48,32,16".split(","))]
+N_WARM, N_IT = int(os.environ.get("PERF_WARM", "25")), int(os.environ.get("PERF_N", "40"))
 
 
-def step(chunk):
-    for i in range(0, B, chunk):
-        X, feat = mag.forward_fused(stft, x[i:i + chunk], return_spectrum=True)
-        stft.invert(X)
+def step(c):
+    for i in range(0, B, c):
+        X, feat = mag.forward_fused(stft, x[i:i + c], return_spectrum=True)
+        y = stft.invert(X)
+    return y
 
 
-for chunk in (1024, 512, 256, 128, 96, 64, 48, 32, 1024):
-    for _ in range(3):
-        step(chunk)
+for c in chunks:
+    for _ in range(N_WARM if c == chunks[0] else 5):
+        step(c)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    n = 10
-    for _ in range(n):
-        step(chunk)
-    e1.record()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(N_IT):
+        step(c)
+    e.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    print("sub-batch %4d clips (%6.1f MB spectrum): %.3f ms per 1024-clip step = %.1f Mframes/s"
-          % (chunk, chunk * 690 * 513 * 8 / 1e6, ms, B * 690 / ms / 1e3), flush=True)
+    ms = s.elapsed_time(e) / N_IT
+    print("chunk %5d clips (spectrum %7.1f MB): %.3f ms per 1024 clips  %.3e frames/s" % (
+        c, c * 690 * 513 * 8 / 1e6, ms, B * 690 / ms * 1e3), flush=True)
