@@ -12,7 +12,6 @@
 // every step of a wavefront reads/writes 64 consecutive elements of one frame row.  Loads do not depend on
 // the recurrence and are unrolled ahead of it.  HBM-bound: 8 (complex) or 4 (phase) bytes in, 4 out per bin.
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 #include "fastmath.h"
 #include <stdint.h>
 #include <type_traits>
@@ -61,7 +60,7 @@ constexpr int kRowsAhead = 8;   // rows requested before the recurrence consumes
 // full of branches and every load is followed by vmcnt(0) -- one row in flight per thread, 3.1 TB/s for the
 // plain angle against 4.9 TB/s for the same bytes read elementwise.
 template <int MODE, bool CPLX, bool WIN, bool NORM>
-__global__ __launch_bounds__(1024) void phase_scan_kernel(ScanParams p) {
+__global__ __launch_bounds__(256) void phase_scan_kernel(ScanParams p) {
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= p.B * p.F) return;
   const long long b = col / p.F, f = col - b * p.F;
@@ -190,7 +189,7 @@ __device__ __forceinline__ void put_phase(const IntParams& p, long long idx, flo
 }
 
 template <int METHOD, bool NORM, bool POLAR>   // SCAN_IF_*; `rescale` = 0 gives the bare fint_* of utils/misc.py
-__global__ __launch_bounds__(1024) void phase_integrate_kernel(IntParams p, int rescale) {
+__global__ __launch_bounds__(256) void phase_integrate_kernel(IntParams p, int rescale) {
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= p.B * p.F) return;
   const long long b = col / p.F, f = col - b * p.F;
@@ -322,13 +321,6 @@ static void launch_scan(int mode, bool cplx, bool win, bool norm, dim3 grid, dim
 
 using namespace at_hip;
 
-static int scan_block_threads() {
-  const char* e = getenv("ACIDS_SCAN_BLOCK");
-  int bt = e ? atoi(e) : 256;
-  if (bt < 64 || bt > 1024 || (bt & 63)) bt = 256;
-  return bt;
-}
-
 static int phase_scan_impl(const float* X_complex, const float* phase, int64_t B, int64_t T, int64_t F, int mode, int bare,
                            const float* frame_window, const float* offset, const float* scale, float* out, int64_t ld_out,
                            void* stream) {
@@ -347,8 +339,7 @@ static int phase_scan_impl(const float* X_complex, const float* phase, int64_t B
     return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
   }
   const long long cols = B * F;
-  const int bt = scan_block_threads();
-  const dim3 grid((unsigned)((cols + bt - 1) / bt)), block(bt);
+  const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
   launch_scan(mode, X_complex != nullptr, frame_window != nullptr, offset != nullptr, grid, block, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
@@ -363,8 +354,7 @@ static int phase_integrate_impl(const float* y, int64_t ld_y, int64_t B, int64_t
   if (method < SCAN_IF_FORWARD || method > SCAN_IF_CENTRAL) return AT_EINVAL;
   IntParams p = {y, out, B, T, F, offset, scale, ld_y, mag};
   const long long cols = B * F;
-  const int bt = scan_block_threads();
-  const dim3 grid((unsigned)((cols + bt - 1) / bt)), block(bt);
+  const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool norm = offset != nullptr;
   void (*kernel)(IntParams, int) = nullptr;
