@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include "fastmath.h"
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "../../include/acids_hip.h"
@@ -59,79 +60,126 @@ constexpr int kRowsAhead = 8;   // rows requested before the recurrence consumes
 // Input kind, weighting and normalisation are template flags: with them as run-time tests the frame loop is
 // full of branches and every load is followed by vmcnt(0) -- one row in flight per thread, 3.1 TB/s for the
 // plain angle against 4.9 TB/s for the same bytes read elementwise.
-template <int MODE, bool CPLX, bool WIN, bool NORM>
-__global__ __launch_bounds__(256) void phase_scan_kernel(ScanParams p) {
-  const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= p.B * p.F) return;
-  const long long b = col / p.F, f = col - b * p.F;
-  const long long base = b * p.T * p.F + f;
+//
+// NC = 1: flattened (clip, bin) columns, 256 per block (any shape).  NC = 2 / 4: ONE BLOCK PER CLIP, thread j walks
+// the NC columns j + k H, H = ceil(F / NC), and the block's wavefronts advance in lockstep (a barrier per batch of rows).
+// Rows of F = 513 floats start 4 bytes further into their 64-byte segment than the row before, so the run of columns
+// a wavefront stores begins and ends inside a segment on almost every row, and whoever owns the neighbouring columns
+// completes that segment at some other time: the memory side sees partial writes (TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B =
+// 3.6 M per launch against 22.7 M whole ones) and the walk runs at 3.4 TB/s where the same walk over 512-float rows runs
+// at 5.1 TB/s (tools/scan_align_probe.py; misaligned LOADS cost nothing).  What did not help: staging the block's rows
+// through LDS to re-cut the stores on line boundaries (2.1 M partial writes left: the block edges); one block per clip
+// without the barrier (3.1 M: the wavefronts drift).  With the whole clip in one block there are no block edges inside a
+// row, the end of row t meets the start of row t + 1 in the same block, and the barrier keeps both halves of every shared
+// segment within L2's reach.  Two columns per thread because 513 columns are 8.02 wavefronts: 257 threads = 5 wavefronts
+// per clip, 1024 clips resident at once.
+template <int MODE, bool CPLX, bool WIN, bool NORM, int NC>
+__global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_scan_kernel(ScanParams p) {
   const long long T = p.T, F = p.F;
+  long long b, fk[NC];
+  bool on[NC];
+  if (NC == 1) {
+    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= p.B * F) return;
+    b = col / F;
+    fk[0] = col - b * F;
+    on[0] = true;
+  } else {
+    b = blockIdx.x;
+    const long long H = (F + NC - 1) / NC;
+    if ((long long)threadIdx.x >= H) return;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const long long f = threadIdx.x + k * H;
+      on[k] = f < F;
+      fk[k] = on[k] ? f : (long long)threadIdx.x;     // a column past the end walks column j again and stores nothing
+    }
+  }
   float off = 0.f, sc = 1.f;
   if (NORM) {
     off = *p.offset;
     sc = *p.scale;
   }
   const bool div = !p.bare;
-  float* out_col = p.out + b * p.T * p.ld_out + f;
+  float* out_row0 = p.out + b * T * p.ld_out;
   const long long ldo = p.ld_out;
-  auto emit = [&](long long t, float v) {
+  auto emit = [&](int k, long long t, float v) {
     if (WIN) v = p.window[t] * v;
     if (NORM) v = (v - off) / sc;
-    out_col[t * ldo] = v;
+    if (NC == 1 || on[k]) out_row0[t * ldo + fk[k]] = v;
   };
   using In = typename std::conditional<CPLX, float2, float>::type;
-  const In* src = (CPLX ? reinterpret_cast<const In*>(p.X) : reinterpret_cast<const In*>(p.phase)) + base;
+  const In* src = (CPLX ? reinterpret_cast<const In*>(p.X) : reinterpret_cast<const In*>(p.phase)) + b * T * F;
   auto to_phase = [](In v) -> float {
     if constexpr (CPLX) return fast_atan2f(v.y, v.x);
     else return v;
   };
-  double acc = 0.0;                 // torch.cumsum's accumulator on CPU
-  float raw_prev = 0.f;
-  float u_prev = 0.f;               // unwrapped phase of frame t-1
-  float u_prev2 = 0.f;              // ... of frame t-2
-  auto step = [&](long long t, In v) {
+  double acc[NC];                   // torch.cumsum's accumulator on CPU
+  float raw_prev[NC];
+  float u_prev[NC];                 // unwrapped phase of frame t-1
+  float u_prev2[NC];                // ... of frame t-2
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    acc[k] = 0.0;
+    raw_prev[k] = u_prev[k] = u_prev2[k] = 0.f;
+  }
+  auto step = [&](int k, long long t, In v) {
     const float raw = to_phase(v);
     if (MODE == SCAN_ANGLE) {
-      emit(t, raw);
+      emit(k, t, raw);
       return;
     }
     if (t == 0) {
-      if (MODE == SCAN_UNWRAP || MODE == SCAN_IF_CENTRAL) emit(0, raw);
-      if (MODE == SCAN_IF_FORWARD) emit(0, (div && T > 1) ? raw / kPi : raw);   // rows [0, T-2] are divided by pi
-      raw_prev = u_prev = raw;
+      if (MODE == SCAN_UNWRAP || MODE == SCAN_IF_CENTRAL) emit(k, 0, raw);
+      if (MODE == SCAN_IF_FORWARD) emit(k, 0, (div && T > 1) ? raw / kPi : raw);   // rows [0, T-2] are divided by pi
+      raw_prev[k] = u_prev[k] = raw;
       return;
     }
-    if (div) acc += (double)unwrap_correction(raw - raw_prev);
-    const float u = raw + (float)acc;
+    if (div) acc[k] += (double)unwrap_correction(raw - raw_prev[k]);
+    const float u = raw + (float)acc[k];
     if (MODE == SCAN_UNWRAP) {
-      emit(t, u);
+      emit(k, t, u);
     } else if (MODE == SCAN_IF_FORWARD) {
-      const float d = (u - u_prev) / 2.0f;
-      emit(t, (div && t < T - 1) ? d / kPi : d);
+      const float d = (u - u_prev[k]) / 2.0f;
+      emit(k, t, (div && t < T - 1) ? d / kPi : d);
     } else if (MODE == SCAN_IF_BACKWARD) {
-      const float d = (u_prev - u) / 2.0f;            // row t-1; rows >= 1 are divided by -pi
-      emit(t - 1, (div && t - 1 >= 1) ? d / (-kPi) : d);
+      const float d = (u_prev[k] - u) / 2.0f;         // row t-1; rows >= 1 are divided by -pi
+      emit(k, t - 1, (div && t - 1 >= 1) ? d / (-kPi) : d);
     } else if (MODE == SCAN_IF_CENTRAL) {
       if (t >= 2) {                                   // interior rows
-        const float d = (u - u_prev2) / 4.0f;
-        emit(t - 1, div ? d / kTwoPi : d);
+        const float d = (u - u_prev2[k]) / 4.0f;
+        emit(k, t - 1, div ? d / kTwoPi : d);
       }
     }
-    raw_prev = raw;
-    u_prev2 = u_prev;
-    u_prev = u;
+    raw_prev[k] = raw;
+    u_prev2[k] = u_prev[k];
+    u_prev[k] = u;
   };
   long long t = 0;
   for (; t + kRowsAhead <= T; t += kRowsAhead) {
-    In v[kRowsAhead];
+    In v[NC][kRowsAhead];
 #pragma unroll
-    for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(t + k) * F];
+    for (int k = 0; k < NC; ++k)
 #pragma unroll
-    for (int k = 0; k < kRowsAhead; ++k) step(t + k, v[k]);
+      for (int r = 0; r < kRowsAhead; ++r) v[k][r] = src[(t + r) * F + fk[k]];
+#pragma unroll
+    for (int r = 0; r < kRowsAhead; ++r)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) step(k, t + r, v[k][r]);
+    // Lockstep.  The wavefronts of a block write neighbouring pieces of the same rows, and the 64-byte segment two of
+    // them share is written whole only if both halves reach L2 close together: left to themselves the wavefronts drift
+    // apart and the memory side sees two partial writes (3.1 M per launch).  One barrier per batch of rows:
+    // 25 k partial writes, no line fetched twice (TCC_EA0_RDREQ 14.0 M -> 11.35 M = the input once), IF.invert 0.84 -> 0.60 ms.
+    if (NC > 1) __syncthreads();
   }
-  for (; t < T; ++t) step(t, src[t * F]);
-  if (MODE == SCAN_IF_BACKWARD) emit(T - 1, (div && T > 1) ? u_prev / (-kPi) : u_prev);   // last row = the phase itself
-  if (MODE == SCAN_IF_CENTRAL && T > 1) emit(T - 1, u_prev);
+  for (; t < T; ++t)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) step(k, t, src[t * F + fk[k]]);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    if (MODE == SCAN_IF_BACKWARD) emit(k, T - 1, (div && T > 1) ? u_prev[k] / (-kPi) : u_prev[k]);   // last row = the phase itself
+    if (MODE == SCAN_IF_CENTRAL && T > 1) emit(k, T - 1, u_prev[k]);
+  }
 }
 
 // Phase(unwrap=False): no recurrence along time, so no column walk -- a flat grid-stride pass (the same bytes
@@ -188,19 +236,38 @@ __device__ __forceinline__ void put_phase(const IntParams& p, long long idx, flo
   }
 }
 
-template <int METHOD, bool NORM, bool POLAR>   // SCAN_IF_*; `rescale` = 0 gives the bare fint_* of utils/misc.py
-__global__ __launch_bounds__(256) void phase_integrate_kernel(IntParams p, int rescale) {
-  const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= p.B * p.F) return;
-  const long long b = col / p.F, f = col - b * p.F;
-  const long long base = b * p.T * p.F + f;
+// NC: columns per thread, as in phase_scan_kernel (NC > 1: one block per clip; forward / backward only)
+template <int METHOD, bool NORM, bool POLAR, int NC>   // SCAN_IF_*; `rescale` = 0 gives the bare fint_* of utils/misc.py
+__global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_integrate_kernel(IntParams p, int rescale) {
+  static_assert(NC == 1 || METHOD != SCAN_IF_CENTRAL, "fint_central walks one column per thread");
   const long long T = p.T, F = p.F;
+  long long b, fk[NC];
+  bool on[NC];
+  if (NC == 1) {
+    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= p.B * F) return;
+    b = col / F;
+    fk[0] = col - b * F;
+    on[0] = true;
+  } else {
+    b = blockIdx.x;
+    const long long H = (F + NC - 1) / NC;
+    if ((long long)threadIdx.x >= H) return;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const long long f = threadIdx.x + k * H;
+      on[k] = f < F;
+      fk[k] = on[k] ? f : (long long)threadIdx.x;
+    }
+  }
+  const long long f = fk[0];
+  const long long base = b * T * F + f;
   float off = 0.f, sc = 1.f;
   if (NORM) {
     off = *p.offset;
     sc = *p.scale;
   }
-  const float* src = p.y + b * p.T * p.ld_y + f;
+  const float* src = p.y + b * T * p.ld_y + f;
   const long long ldy = p.ld_y;
   // de-normalised, re-scaled value of input row t (spectral_repr.py:362-370)
   auto prep = [&](long long t, float v) {
@@ -215,23 +282,34 @@ __global__ __launch_bounds__(256) void phase_integrate_kernel(IntParams p, int r
   if (METHOD == SCAN_IF_FORWARD || METHOD == SCAN_IF_BACKWARD) {
     // forward: rows >= 1 doubled, running sum from row 0; backward: the mirror image from row T-1
     constexpr bool FWD = (METHOD == SCAN_IF_FORWARD);
-    double acc = 0.0;
-    auto step = [&](long long s, float v) {          // s = position in scan order, row = FWD ? s : T-1-s
+    double acc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = 0.0;
+    const float* src_row0 = p.y + b * T * ldy;
+    const long long out_row0 = b * T * F;
+    auto step = [&](int k, long long s, float v) {   // s = position in scan order, row = FWD ? s : T-1-s
       const long long row = FWD ? s : T - 1 - s;
       v = prep(row, v);
       if (s >= 1) v = v * 2.0f;
-      acc += (double)v;
-      put_phase<POLAR>(p, base + row * F, (float)acc);
+      acc[k] += (double)v;
+      if (NC == 1 || on[k]) put_phase<POLAR>(p, out_row0 + row * F + fk[k], (float)acc[k]);
     };
     long long s = 0;
     for (; s + kRowsAhead <= T; s += kRowsAhead) {
-      float v[kRowsAhead];
+      float v[NC][kRowsAhead];
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(FWD ? s + k : T - 1 - s - k) * ldy];
+      for (int k = 0; k < NC; ++k)
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) step(s + k, v[k]);
+        for (int r = 0; r < kRowsAhead; ++r) v[k][r] = src_row0[(FWD ? s + r : T - 1 - s - r) * ldy + fk[k]];
+#pragma unroll
+      for (int r = 0; r < kRowsAhead; ++r)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) step(k, s + r, v[k][r]);
+      if (NC > 1) __syncthreads();     // lockstep: see phase_scan_kernel
     }
-    for (; s < T; ++s) step(s, src[(FWD ? s : T - 1 - s) * ldy]);
+    for (; s < T; ++s)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) step(k, s, src_row0[(FWD ? s : T - 1 - s) * ldy + fk[k]]);
   } else {
     // fint_central (utils/misc.py:96-104), statement by statement.  Rows the reference never writes stay 0.
     auto z = [&](long long t) { return prep(t, src[t * ldy]); };
@@ -292,10 +370,26 @@ __global__ __launch_bounds__(256) void polar_to_complex_kernel(const float* __re
 }
 
 // run-time options -> template flags
+// columns per thread of the clip-per-block layout (0: flattened columns): rows that are not a whole number of 64-byte
+// segments, long enough for a block of their own, short enough for 1024 threads x 4
+static int clip_block_columns(long long F, long long B, int elem_bytes) {
+  if (getenv("ACIDS_SCAN_FLAT")) return 0;
+  if ((F * elem_bytes) % 64 == 0 || F < 256 || B < 64) return 0;
+  return F <= 2048 ? 2 : F <= 4096 ? 4 : 0;
+}
+static unsigned clip_block_threads(long long F, int nc) { return (unsigned)((((F + nc - 1) / nc) + 63) / 64 * 64); }
+
+template <int MODE, bool CPLX, bool WIN, bool NORM>
+static void launch_scan4(dim3 grid, dim3 block, hipStream_t s, const ScanParams& p) {
+  const int nc = clip_block_columns(p.F, p.B, 4);
+  if (nc == 2) hipLaunchKernelGGL((phase_scan_kernel<MODE, CPLX, WIN, NORM, 2>), dim3((unsigned)p.B), dim3(clip_block_threads(p.F, 2)), 0, s, p);
+  else if (nc == 4) hipLaunchKernelGGL((phase_scan_kernel<MODE, CPLX, WIN, NORM, 4>), dim3((unsigned)p.B), dim3(clip_block_threads(p.F, 4)), 0, s, p);
+  else hipLaunchKernelGGL((phase_scan_kernel<MODE, CPLX, WIN, NORM, 1>), grid, block, 0, s, p);
+}
 template <int MODE, bool CPLX, bool WIN>
 static void launch_scan3(bool norm, dim3 grid, dim3 block, hipStream_t s, const ScanParams& p) {
-  if (norm) hipLaunchKernelGGL((phase_scan_kernel<MODE, CPLX, WIN, true>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((phase_scan_kernel<MODE, CPLX, WIN, false>), grid, block, 0, s, p);
+  if (norm) launch_scan4<MODE, CPLX, WIN, true>(grid, block, s, p);
+  else launch_scan4<MODE, CPLX, WIN, false>(grid, block, s, p);
 }
 template <int MODE>
 static void launch_scan1(bool cplx, bool win, bool norm, dim3 grid, dim3 block, hipStream_t s, const ScanParams& p) {
@@ -358,13 +452,27 @@ static int phase_integrate_impl(const float* y, int64_t ld_y, int64_t B, int64_t
   hipStream_t s = (hipStream_t)stream;
   const bool norm = offset != nullptr;
   void (*kernel)(IntParams, int) = nullptr;
-  if (method == SCAN_IF_FORWARD)
-    kernel = norm ? phase_integrate_kernel<SCAN_IF_FORWARD, true, POLAR> : phase_integrate_kernel<SCAN_IF_FORWARD, false, POLAR>;
+  const int nc = method == SCAN_IF_CENTRAL ? 0 : clip_block_columns(F, B, POLAR ? 8 : 4);
+  dim3 g = grid, blk = block;
+  if (nc) {
+    g = dim3((unsigned)B);
+    blk = dim3(clip_block_threads(F, nc));
+  }
+  if (method == SCAN_IF_FORWARD && nc == 2)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_FORWARD, true, POLAR, 2> : phase_integrate_kernel<SCAN_IF_FORWARD, false, POLAR, 2>;
+  else if (method == SCAN_IF_FORWARD && nc == 4)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_FORWARD, true, POLAR, 4> : phase_integrate_kernel<SCAN_IF_FORWARD, false, POLAR, 4>;
+  else if (method == SCAN_IF_BACKWARD && nc == 2)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_BACKWARD, true, POLAR, 2> : phase_integrate_kernel<SCAN_IF_BACKWARD, false, POLAR, 2>;
+  else if (method == SCAN_IF_BACKWARD && nc == 4)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_BACKWARD, true, POLAR, 4> : phase_integrate_kernel<SCAN_IF_BACKWARD, false, POLAR, 4>;
+  else if (method == SCAN_IF_FORWARD)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_FORWARD, true, POLAR, 1> : phase_integrate_kernel<SCAN_IF_FORWARD, false, POLAR, 1>;
   else if (method == SCAN_IF_BACKWARD)
-    kernel = norm ? phase_integrate_kernel<SCAN_IF_BACKWARD, true, POLAR> : phase_integrate_kernel<SCAN_IF_BACKWARD, false, POLAR>;
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_BACKWARD, true, POLAR, 1> : phase_integrate_kernel<SCAN_IF_BACKWARD, false, POLAR, 1>;
   else
-    kernel = norm ? phase_integrate_kernel<SCAN_IF_CENTRAL, true, POLAR> : phase_integrate_kernel<SCAN_IF_CENTRAL, false, POLAR>;
-  hipLaunchKernelGGL(kernel, grid, block, 0, s, p, rescale);
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_CENTRAL, true, POLAR, 1> : phase_integrate_kernel<SCAN_IF_CENTRAL, false, POLAR, 1>;
+  hipLaunchKernelGGL(kernel, g, blk, 0, s, p, rescale);
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 

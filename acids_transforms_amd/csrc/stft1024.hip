@@ -333,10 +333,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   };
   long long t_cur = t0;
   float cm[CMBUF ? CMBUF : 1][8];   // features of frames t_cur-7 .. t_cur (sliding), one row per pass
+  int cm_held[CMBUF ? CMBUF : 1];   // frames of the window that are not stored yet (per lane: flush points differ)
 #pragma unroll
-  for (int q = 0; q < (CMBUF ? CMBUF : 1); ++q)
+  for (int q = 0; q < (CMBUF ? CMBUF : 1); ++q) {
+    cm_held[q] = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) cm[q][k] = 0.f;
+  }
   // Normalize.forward is (x - offset) / scale (norm.py:40-41); here the quotient is a multiplication by the
   // reciprocal taken once per wave (<= 1.5 ulp from the exact division, against the 1e-5 bar): the exact fp32
   // division costs a dozen VALU instructions per feature in a kernel whose epilogue is issue-bound
@@ -526,19 +529,29 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
           }
         }
         if constexpr (CMROW >= 0) {
-          if (((t_cur & 7) == 7 || t_cur == t1 - 1) && f >= 0) {
-            // frames [first, t_cur] of the window are new since the last flush (or the start of the run)
-            long long first = t_cur & ~7LL;
-            if (first < t0) first = t0;
-            float* dst = p.feat + ((long long)b * p.bank.n_filters + f) * p.T + (t_cur - 7);
-            if (first == t_cur - 7 && !(p.T & 1)) {         // whole group, rows 8-byte aligned
+          // Every lane flushes its window when the eight frames it holds end on a 32-byte boundary of its own output row
+          // ((.., N, T) rows start at arbitrary multiples of 4 bytes), so that a store covers whole 32-byte sectors; a
+          // window cut by the frame index instead straddles two sectors on most rows and both are written partially
+          // (TCC_EA0_WRREQ 16.2 M per launch, 4.8 M of them whole 64-byte requests).  At the end of the run: whatever it holds.
+          ++cm_held[CMROW];
+          if (f >= 0) {
+            const long long e = ((long long)b * p.bank.n_filters + f) * p.T + t_cur + 1;   // one past frame t_cur
+            if ((e & 7) == 0 || t_cur == t1 - 1) {
+              float* dst = p.feat + e - 8;
+              if (cm_held[CMROW] >= 8) {
+                if ((e & 3) == 0) {
+                  reinterpret_cast<float4*>(dst)[0] = make_float4(cm[CMROW][0], cm[CMROW][1], cm[CMROW][2], cm[CMROW][3]);
+                  reinterpret_cast<float4*>(dst)[1] = make_float4(cm[CMROW][4], cm[CMROW][5], cm[CMROW][6], cm[CMROW][7]);
+                } else {
 #pragma unroll
-              for (int k = 0; k < 8; k += 2)
-                *reinterpret_cast<float2*>(dst + k) = make_float2(cm[CMROW][k], cm[CMROW][k + 1]);
-            } else {
+                  for (int k = 0; k < 8; ++k) dst[k] = cm[CMROW][k];
+                }
+              } else {
 #pragma unroll
-              for (int k = 0; k < 8; ++k)
-                if (t_cur - 7 + k >= first) dst[k] = cm[CMROW][k];
+                for (int k = 0; k < 8; ++k)
+                  if (k >= 8 - cm_held[CMROW]) dst[k] = cm[CMROW][k];
+              }
+              cm_held[CMROW] = 0;
             }
           }
         }

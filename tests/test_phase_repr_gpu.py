@@ -160,6 +160,43 @@ def test_against_oracle_random_shapes(dev):
         ops.phase_scan(torch.zeros(5, dtype=torch.complex64, device=dev), "unwrap")
 
 
+@pytest.mark.parametrize("shape", [(64, 19, 513), (70, 8, 257), (65, 1, 513), (64, 17, 1025), (64, 9, 2049), (66, 23, 300)])
+def test_clip_per_block_scans_equal_flat_layout_and_oracle(dev, shape):
+    """>= 64 clips with rows of >= 256 bins that are not whole 64-byte segments take the one-block-per-clip layout
+    (2 or 4 columns per thread, wavefronts in lockstep): bit-identical to the flattened-column layout
+    (ACIDS_SCAN_FLAT=1) for every mode, bit-identical to the oracle on real input, 1e-5 from it through atan2."""
+    import os
+    gen = torch.Generator().manual_seed(sum(shape))
+    X = (torch.randn(*shape, generator=gen) * torch.exp(2j * np.pi * torch.rand(*shape, generator=gen))).to(torch.complex64)
+    y = torch.randn(*shape, generator=gen) * 3.0
+    Xd, yd = X.to(dev), y.to(dev)
+    win = torch.rand(shape[-2], generator=gen).to(dev)
+    off, sc = torch.tensor(0.3, device=dev), torch.tensor(1.7, device=dev)
+
+    def run():
+        out = {"unwrap_c": ops.phase_scan(Xd, "unwrap"), "unwrap_r": M.unwrap(yd)}
+        for m in METHODS:
+            out["if_" + m] = ops.phase_scan(Xd, m, frame_window=win, offset=off, scale=sc)
+            out["fdiff_" + m] = getattr(M, "fdiff_" + m)(yd)
+            out["fint_" + m] = getattr(M, "fint_" + m)(yd)
+            out["int_" + m] = ops.phase_integrate(yd, m, offset=off, scale=sc)
+        return {k: cpu(v) for k, v in out.items()}
+
+    got = run()
+    os.environ["ACIDS_SCAN_FLAT"] = "1"
+    try:
+        flat = run()
+    finally:
+        del os.environ["ACIDS_SCAN_FLAT"]
+    for k in got:
+        assert torch.equal(got[k], flat[k]), (k, shape)
+    assert torch.equal(got["unwrap_r"], O.unwrap(y))
+    assert rel_max(got["unwrap_c"].numpy(), O.unwrap(X.angle()).numpy()) < TOL
+    for m in METHODS:
+        assert torch.equal(got["fdiff_" + m], O.fdiff(y, m)), m
+        assert torch.equal(got["fint_" + m], O.fint(y, m)), m
+
+
 def test_full_size_round_trip_properties(dev):
     """BASELINE config-2 size (1024 clips would be 1.4 GB per tensor; 256 clips x 690 frames x 513 bins here):
     size-independent properties instead of an oracle run --

@@ -16,6 +16,8 @@ n_cases = int(os.environ.get("FUZZ_CASES", "80"))
 checked = 0
 for i in range(n_cases):
     shape = tuple(int(v) for v in rng.randint(1, 6, size=int(rng.randint(0, 3)))) + (int(rng.randint(1, 60)), int(rng.randint(1, 40)))
+    if i % 4 == 3:      # one block per clip (>= 64 clips, rows of >= 256 bins that are not whole 64-byte segments): 2 / 4 columns per thread
+        shape = (int(rng.randint(64, 80)), int(rng.randint(1, 40)), int(rng.choice([257, 300, 513, 1025, 2049, 2050, 4001])))
     scale = float(rng.choice([0.5, 3.0, 10.0, 100.0, 1e4]))
     x = torch.from_numpy((rng.randn(*shape) * scale).astype(np.float32))
     xd = x.to(dev)
