@@ -1,0 +1,27 @@
+"""Polar / PolarIF forward and invert at 1024 x 690 x 513 (ACIDS_SCAN_FLAT=1: flattened-column scans)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import acids_transforms_amd as A
+dev = torch.device("cuda:0")
+B, T, F = 1024, 690, 513
+X = torch.view_as_complex(torch.randn(B, T, F, 2, device=dev))
+
+
+def timeit(fn, n=10, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+for name, tr in (("polar", A.Polar()), ("polar_if", A.PolarIF())):
+    tr = tr.to(dev)
+    tr.scale_data(X[:4])
+    y = tr(X)
+    print("%-9s forward %.3f ms   invert %.3f ms   [%s]" % (name, timeit(lambda: tr(X)), timeit(lambda: tr.invert(y)),
+                                                           "flat" if os.environ.get("ACIDS_SCAN_FLAT") else "clip blocks"), flush=True)
+    del y

@@ -5,7 +5,7 @@ TAG=${1:-r01}
 REPO=$(pwd); OUT=$REPO/gpurun_out/sec_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o sec -- python3 $REPO/tools/perf_all.py fwd,inv,polar,mel128,melbf16,mel513,fused513,fused2,mfcc40,phase,polarfwd,stftpolar,sinebank,sizes > $OUT/perf_all.log 2> $OUT/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o sec -- python3 $REPO/tools/perf_all.py fwd,inv,polar,mel128,melbf16,mel513,fused513,fused2,mfcc40,dct40,phase,polarfwd,stftpolar,sinebank,sizes > $OUT/perf_all.log 2> $OUT/err.log
 cd $REPO
 python3 - "$OUT" "$TAG" > gpurun_out/secondary_$TAG.md <<'PY'
 import csv, glob, sys, os
