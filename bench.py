@@ -45,10 +45,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="STFT and Magnitude as two kernels")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
-    ap.add_argument("--settle-steps", type=int, default=40,
+    ap.add_argument("--settle-steps", type=int, default=-1,
                     help="untimed steps run BEFORE the --warmup steps so that the timed region sees the chip's sustained "
                          "clocks (a fresh process runs its first two steps at boost clock, is then clamped ~35 %% below by "
-                         "the power controller and recovers over ~25 steps: tools/ramp_probe.py); 0 = none")
+                         "the power controller and recovers over 25 to 60 steps: tools/ramp_probe.py); -1 = until three "
+                         "consecutive 10-step averages agree within 1.5 %% (at least 40, at most 600 steps); 0 = none")
     ap.add_argument("--pghi-clips", type=int, default=1024, help="clips for the DGT+PGHI round-trip side measurement")
     ap.add_argument("--streams", type=int, default=256, help="concurrent streams for the RealtimeDGT side measurement")
     ap.add_argument("--stream-steps", type=int, default=1000, help="steps per cell of the streaming matrix")
@@ -402,6 +403,13 @@ def main():
     last = {}
 
     def step(record=False):
+        # The previous step's outputs are released BEFORE this step allocates its own, so every step writes the same three
+        # blocks of the caching allocator.  Holding them across the call (as this function used to) makes the allocator
+        # alternate between two sets of blocks, and the sets are not equally fast: same kernels, same box, 0.81-0.84 ms
+        # into one spectrum buffer and 0.87-0.89 ms into the other (tools/placement_probe.py; a process's earlier
+        # allocations are the faster ones, tools/placement_probe2.py: 0.677 / 0.685 / 0.685 / 0.703 ms for four buffers
+        # in allocation order) -- the timed steps then alternated 1.49 / 1.60 ms.
+        last.clear()
         e = None
         if record:
             e = [ev() for _ in range(4)]
@@ -502,8 +510,28 @@ def main():
 
     # settle: the power controller's transient of a fresh process is over before the W warm-up steps start
     # (reported as `settle_steps`; the W warm-up steps and the K timed steps follow as the contract says)
-    for _ in range(max(0, args.settle_steps)):
-        step()
+    settled = 0
+    if args.settle_steps >= 0:
+        for _ in range(args.settle_steps):
+            step()
+        settled = args.settle_steps
+    else:
+        # adaptive: 10-step chunks timed with events; the host waits for chunk k while chunk k + 1 is already queued,
+        # so the GPU never idles (an idle gap is itself a transient: the first step after one runs ~12 % slow)
+        marks = [ev()]
+        marks[0].record()
+        means = []
+        while settled < 600:
+            for _ in range(10):
+                step()
+            settled += 10
+            marks.append(ev())
+            marks[-1].record()
+            if len(marks) >= 3:
+                marks[-2].synchronize()
+                means.append(marks[-3].elapsed_time(marks[-2]) / 10.0)
+            if settled >= 40 and len(means) >= 3 and max(means[-3:]) <= 1.015 * min(means[-3:]):
+                break
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -887,9 +915,9 @@ def main():
         "world_size_observed": dist.get_world_size() if use_dist else 1, "backend": backend,
         "roofline": roof,
         "kernels": kernels,
-        "settle_steps": max(0, args.settle_steps),
+        "settle_steps": settled,
         "timed_step_ms": {"first": step_ms_events[0], "last": step_ms_events[-1], "min": min(step_ms_events),
-                          "max": max(step_ms_events),
+                          "max": max(step_ms_events), "all": step_ms_events,
                           "note": "per-step kernel time (HIP events) inside the timed region: flat = steady state"},
     }
     result.update(extras)
