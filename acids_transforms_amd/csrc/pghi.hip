@@ -528,6 +528,26 @@ __device__ __forceinline__ int coop_bubble(const HEAP& H, int n, int lane, u64 a
   const int last_level = 31 - __clz((unsigned)n | 1u);
   int limit = last_level >= 1 ? ((last_level - 1) % 5) + 1 : 5;
   bool first = true;
+#ifndef AT_PGHI_NO_ROOT_STEP
+  if (limit == 1) {
+    // A first round of ONE level (last level 1, 6, 11 or 16 -- a third of all pops on dense spectra sit at 16) is the
+    // root choosing between its two children: both are in `top63` (positions 1 and 2 on lanes 2 and 3), so the round is
+    // two readlanes, one compare (heapq.py:33: the right child unless left < right; a missing child reads +inf) and one
+    // store, all on the scalar side, instead of the 64-lane machinery below and its LDS round trip.
+    const u64 v1 = readlane64(top63, 2);
+    const u64 v2 = (2 < n) ? readlane64(top63, 3) : kInf;
+    const bool left = item_key(v1) < item_key(v2);
+    const u64 vc = left ? v1 : v2;
+    pos = left ? 1 : 2;
+    if (lane == 0) H.store(0, vc);
+    if (2 * pos + 1 >= n) {
+      leaf_old = vc;
+      return pos;
+    }
+    limit = 5;
+    first = false;
+  }
+#endif
   for (;;) {
     // subtree under the hole: local node `lane` (1..63) <-> global index g
     const int g = ((pos + 1) << lvl) - 1 + off;           // < 2^25: heap positions are < T F < 2^31 >> 5
