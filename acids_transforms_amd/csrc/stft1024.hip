@@ -442,8 +442,43 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
       }
       prow += phase_ld;
     }
+    // channel-major register window of pass CMROW: take this frame's value, flush when the window ends on a 32-byte
+    // boundary of the lane's own (.., N, T) row or at the end of the run
+    auto cm_push = [&](auto cmsel, int f, float value) {
+      constexpr int CMROW = decltype(cmsel)::value;
+      if (f >= 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cm[CMROW][k] = cm[CMROW][k + 1];
+        cm[CMROW][7] = value;
+      }
+      // Every lane flushes its window when the eight frames it holds end on a 32-byte boundary of its own output row
+      // ((.., N, T) rows start at arbitrary multiples of 4 bytes), so that a store covers whole 32-byte sectors; a
+      // window cut by the frame index instead straddles two sectors on most rows and both are written partially
+      // (TCC_EA0_WRREQ 16.2 M per launch, 4.8 M of them whole 64-byte requests).  At the end of the run: whatever it holds.
+      ++cm_held[CMROW];
+      if (f >= 0) {
+        const long long e = ((long long)b * p.bank.n_filters + f) * p.T + t_cur + 1;   // one past frame t_cur
+        if ((e & 7) == 0 || t_cur == t1 - 1) {
+          float* dst = p.feat + e - 8;
+          if (cm_held[CMROW] >= 8) {
+            if ((e & 3) == 0) {
+              reinterpret_cast<float4*>(dst)[0] = make_float4(cm[CMROW][0], cm[CMROW][1], cm[CMROW][2], cm[CMROW][3]);
+              reinterpret_cast<float4*>(dst)[1] = make_float4(cm[CMROW][4], cm[CMROW][5], cm[CMROW][6], cm[CMROW][7]);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) dst[k] = cm[CMROW][k];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (k >= 8 - cm_held[CMROW]) dst[k] = cm[CMROW][k];
+          }
+          cm_held[CMROW] = 0;
+        }
+      }
+    };
     if constexpr (MEL != 0 && FQ0 > 0) {
-      static_assert(SP == 2 && !CMBUF && !POLAR, "fixed-length epilogue: two passes, row-major features");
+      static_assert(SP == 2 && (CMBUF == 0 || CMBUF == 2) && !POLAR, "fixed-length epilogue: two passes, no phase rows");
       float* absrow = reinterpret_cast<float*>(lds);
       wave_lds_sync();
 #pragma unroll
@@ -463,8 +498,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
       float f1v = band_contrast_fast(sum1, FC, p.eps);
       f0v = (f0v - mel_off) * mel_inv;      // no Normalize: offset 0, reciprocal 1 -- the identity, bit for bit
       f1v = (f1v - mel_off) * mel_inv;
-      if (sp_f[0] >= 0) frow[sp_f[0]] = f0v;
-      if (sp_f[1] >= 0) frow[sp_f[1]] = f1v;
+      if constexpr (CMBUF == 2) {
+        cm_push(std::integral_constant<int, 0>(), sp_f[0], f0v);
+        cm_push(std::integral_constant<int, 1>(), sp_f[1], f1v);
+      } else {
+        if (sp_f[0] >= 0) frow[sp_f[0]] = f0v;
+        if (sp_f[1] >= 0) frow[sp_f[1]] = f1v;
+      }
       wave_lds_sync();
       frow += feat_ld;
       ++t_cur;
@@ -519,42 +559,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
           acc = fwd_contrast(acc, p.contrast, p.eps);
           if (p.offset) acc = (acc - mel_off) * mel_inv;
           if constexpr (CMROW >= 0) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) cm[CMROW][k] = cm[CMROW][k + 1];
-            cm[CMROW][7] = acc;
+            // parked in the register window below
           } else if (p.feat_channel_major) {
             p.feat[((long long)b * p.bank.n_filters + f) * p.T + t_cur] = acc;
           } else {
             frow[f] = acc;
           }
         }
-        if constexpr (CMROW >= 0) {
-          // Every lane flushes its window when the eight frames it holds end on a 32-byte boundary of its own output row
-          // ((.., N, T) rows start at arbitrary multiples of 4 bytes), so that a store covers whole 32-byte sectors; a
-          // window cut by the frame index instead straddles two sectors on most rows and both are written partially
-          // (TCC_EA0_WRREQ 16.2 M per launch, 4.8 M of them whole 64-byte requests).  At the end of the run: whatever it holds.
-          ++cm_held[CMROW];
-          if (f >= 0) {
-            const long long e = ((long long)b * p.bank.n_filters + f) * p.T + t_cur + 1;   // one past frame t_cur
-            if ((e & 7) == 0 || t_cur == t1 - 1) {
-              float* dst = p.feat + e - 8;
-              if (cm_held[CMROW] >= 8) {
-                if ((e & 3) == 0) {
-                  reinterpret_cast<float4*>(dst)[0] = make_float4(cm[CMROW][0], cm[CMROW][1], cm[CMROW][2], cm[CMROW][3]);
-                  reinterpret_cast<float4*>(dst)[1] = make_float4(cm[CMROW][4], cm[CMROW][5], cm[CMROW][6], cm[CMROW][7]);
-                } else {
-#pragma unroll
-                  for (int k = 0; k < 8; ++k) dst[k] = cm[CMROW][k];
-                }
-              } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                  if (k >= 8 - cm_held[CMROW]) dst[k] = cm[CMROW][k];
-              }
-              cm_held[CMROW] = 0;
-            }
-          }
-        }
+        if constexpr (CMROW >= 0) cm_push(cmsel, f, acc);
       };
       if constexpr (CMBUF >= 1) {            // the launcher picks CMBUF == n_passes (1 or 2)
         one_pass(0, std::integral_constant<int, 0>());
@@ -1066,6 +1078,15 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     if (hop == 256 && !polar && !phase && !feat_channel_major && !out && bank->n_passes == 2 && contrast == 2 && power2 &&
         bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && !getenv("ACIDS_GENERIC_EPILOGUE")) {
       kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 0, false, 2, 2, 8, 2, false, false, 3, 2, true>;
+      fq_logpow = true;
+    }
+    // MelSpectrogram (the reference's MFCC: |X|^2 on the 128-filter bank, no contrast, channel-major (.., N, T) output,
+    // spectrum never stored) on the same fixed-length epilogue, its two results parked in the register windows
+    if (hop == 256 && !polar && !phase && feat_channel_major && !out && bank->n_passes == 2 && contrast == 0 && power2 &&
+        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && !getenv("ACIDS_GENERIC_EPILOGUE")) {
+      // 4-wave blocks at three waves per SIMD (142 registers); with the pass twiddles in registers as well (HYB = 3) the
+      // two windows no longer fit and spill (0.75 ms against 0.72; the run-time-length epilogue: 0.755)
+      kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 2, false, 2, 2, 8, 2, false, false, 0, 0, true>;
       fq_logpow = true;
     }
     if (hop == 128) {
