@@ -1,6 +1,7 @@
 // pointwise.hip -- small elementwise kernels around the spectral path.
 //   angle            x_fft.angle()                 reference stft.py:103, dgt.py:69, dgt.py:336   (K2)
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "fastmath.h"
 #include <stdint.h>
 #include <type_traits>
@@ -131,6 +132,42 @@ __global__ __launch_bounds__(256) void cartesian_pack_kernel(const float2* __res
       f -= (Idx)F;
       ++r;
     }
+  }
+}
+
+// The same with ROWS-PER-BLOCK chunks and the block's wavefronts in lockstep, for rows that are not whole 64-byte
+// segments (F = 513): in the grid-stride form above a wavefront's 256 bytes of a real (or imaginary) row begin and end
+// inside a segment, and the segment's other half comes from the neighbouring block -- on another XCD, behind another
+// L2 -- so the memory side sees two partial writes per block edge (phase_repr.hip has the counters of the same effect in
+// the scans).  Here a block owns kPackRows consecutive frames (2 kPackRows output rows, contiguous), its wavefronts walk
+// them together (a barrier per 256 elements), and only the chunk's two ends are shared with other blocks.
+constexpr int kPackRows = 8;
+__global__ __launch_bounds__(256) void cartesian_pack_rows_kernel(const float2* __restrict__ x, long long rows, int F,
+                                                                  const float* re_off, const float* re_sc, const float* im_off,
+                                                                  const float* im_sc, float* __restrict__ out) {
+  const float ro = re_off ? *re_off : 0.f, rs = re_off ? *re_sc : 1.f;
+  const float io = im_off ? *im_off : 0.f, is = im_off ? *im_sc : 1.f;
+  const long long r0 = (long long)blockIdx.x * kPackRows;
+  const int nr = (int)(rows - r0 < kPackRows ? rows - r0 : kPackRows);
+  const int n = nr * F;
+  const float2* src = x + r0 * F;
+  float* dst0 = out + 2 * r0 * F;
+  const int dr = 256 / F, df = 256 - dr * F;
+  int r = (int)threadIdx.x / F, f = (int)threadIdx.x - r * F;
+  for (int i = threadIdx.x; i < ((n + 255) & ~255); i += 256) {
+    if (i < n) {
+      const float2 v = src[i];
+      float* dst = dst0 + (long long)(2 * r) * F + f;
+      dst[0] = re_off ? (v.x - ro) / rs : v.x;
+      dst[F] = im_off ? (v.y - io) / is : v.y;
+    }
+    r += dr;
+    f += df;
+    if (f >= F) {
+      f -= F;
+      ++r;
+    }
+    __syncthreads();
   }
 }
 
@@ -333,6 +370,13 @@ int at_cartesian_pack(const float* x_complex, int64_t rows, int F, const float* 
   if ((re_offset == nullptr) != (re_scale == nullptr) || (im_offset == nullptr) != (im_scale == nullptr)) return AT_EINVAL;
   const long long n = (long long)rows * F;
   const unsigned grid = grid_for(n, 256) * 4;      // grid_for caps at 8 blocks per CU: one element per thread and trip here
+  if ((F * 4) % 64 != 0 && F >= 64 && rows >= 64 && (rows + kPackRows - 1) / kPackRows < (1LL << 31) &&
+      !getenv("ACIDS_CARTESIAN_FLAT")) {
+    hipLaunchKernelGGL(cartesian_pack_rows_kernel, dim3((unsigned)((rows + kPackRows - 1) / kPackRows)), dim3(256), 0,
+                       (hipStream_t)stream, (const float2*)x_complex, (long long)rows, F, re_offset, re_scale, im_offset,
+                       im_scale, stacked);
+    return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
+  }
   if (n < (1LL << 32))
     hipLaunchKernelGGL(cartesian_pack_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float2*)x_complex,
                        (long long)rows, F, re_offset, re_scale, im_offset, im_scale, stacked);

@@ -292,7 +292,7 @@ def test_polar_one_pass_equals_parts(dev):
         p2(Xd)
 
 
-@pytest.mark.parametrize("shape", [(3, 2, 21, 513), (2, 1, 513), (1, 2, 129), (4, 33, 1025), (7, 257)])
+@pytest.mark.parametrize("shape", [(3, 2, 21, 513), (2, 1, 513), (1, 2, 129), (4, 33, 1025), (7, 257), (9, 67, 513), (70, 300)])
 def test_cartesian_and_polarif_work_inside_the_stacked_tensor(dev, shape):
     """Cartesian is one pack / unpack kernel, PolarIF's halves are written into / read from the stacked tensor in place
     (banded magnitude with a row stride, IF scan with a row stride, integration fused with mag * exp(i phase)): the

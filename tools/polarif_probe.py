@@ -18,10 +18,10 @@ def timeit(fn, n=10, warm=5):
     return s.elapsed_time(e) / n
 
 
-for name, tr in (("polar", A.Polar()), ("polar_if", A.PolarIF())):
+for name, tr in (("polar", A.Polar()), ("polar_if", A.PolarIF()), ("cartesian", A.Cartesian())):
     tr = tr.to(dev)
     tr.scale_data(X[:4])
     y = tr(X)
     print("%-9s forward %.3f ms   invert %.3f ms   [%s]" % (name, timeit(lambda: tr(X)), timeit(lambda: tr.invert(y)),
-                                                           "flat" if os.environ.get("ACIDS_SCAN_FLAT") else "clip blocks"), flush=True)
+                                                           "flat" if (os.environ.get("ACIDS_SCAN_FLAT") or os.environ.get("ACIDS_CARTESIAN_FLAT")) else "default"), flush=True)
     del y
