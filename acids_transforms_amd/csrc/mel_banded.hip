@@ -135,6 +135,16 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
     ph_off = *p.ph_offset;
     ph_sc = *p.ph_scale;
   }
+  // Normalize.forward is (x - offset) / scale (norm.py:40-41); as in the fused epilogues the quotient is a multiplication
+  // by the reciprocal taken once per wave (<= 1.5 ulp from the exact division, against the 1e-5 bar)
+#ifdef AT_BANDED_EXACT_DIV
+#define AT_NORM(v, o, s, inv) (((v) - (o)) / (s))
+#else
+#define AT_NORM(v, o, s, inv) (((v) - (o)) * (inv))
+#endif
+  const float inv_sc = 1.0f / sc, ph_inv = 1.0f / ph_sc;
+  (void)inv_sc;
+  (void)ph_inv;
   const long long w_id = (long long)blockIdx.x * (n_thr >> 6) + wave;
   long long r = w_id * p.rows_per_wave;
   long long r_end = r + p.rows_per_wave;
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
           const int kk = lane + 64 * m;
           if ((EXACT && m + 1 < NSEG) || kk < p.K) {
             float ph = fast_atan2f(cur[m].y, cur[m].x);
-            if (p.ph_offset) ph = (ph - ph_off) / ph_sc;
+            if (p.ph_offset) ph = AT_NORM(ph, ph_off, ph_sc, ph_inv);
             p.phase_out[r * p.ld_phase + kk] = ph;
           }
         }
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
         acc = band_dot(a, w, quads);
         w += quads * 64;
         acc = banded_contrast_fwd(acc, p.contrast, p.eps);
-        if (p.offset) acc = (acc - off) / sc;
+        if (p.offset) acc = AT_NORM(acc, off, sc, inv_sc);
 #pragma unroll
         for (int k = 0; k < 7; ++k) cm[q][k] = cm[q][k + 1];
         cm[q][7] = acc;
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
       if (f >= 0) {
         if (!p.inverse) {
           acc = banded_contrast_fwd(acc, p.contrast, p.eps);
-          if (p.offset) acc = (acc - off) / sc;
+          if (p.offset) acc = AT_NORM(acc, off, sc, inv_sc);
         }
         if (p.phase_in) {
           float ph = p.phase_in[r * p.ld_phase + f];
