@@ -794,11 +794,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WLDS ? 4 : 
           const int ch = 16 * mt + 8 * hi + 4 * h + i;
           float a = __uint_as_float(sw[h]);
           if (p.offset) a = (a - off) / sc;
-#ifdef AT_DCT_NOSTORE
-          if (row_ok && ch < p.N && a == 12345.678f) {
-#else
           if (row_ok && ch < p.N) {
-#endif
             float* dst = base + ch * ch_stride;
             if (NT) __builtin_nontemporal_store(a, dst);
             else *dst = a;
