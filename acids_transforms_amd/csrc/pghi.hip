@@ -111,10 +111,26 @@ __global__ __launch_bounds__(256) void pghi_grad_offline_kernel(GradParams p) {
   const float pi_f = (float)3.14159265358979323846;
   const long long per = (long long)p.T * p.F;
   const long long total = p.B * per;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long b = i / per;
-    const long long r = i - b * per;
-    const int t = (int)(r / p.F), k = (int)(r - (long long)t * p.F);
+  // (clip, frame, bin) of the flat index are carried along the grid stride: two 64-bit divisions per thread instead of
+  // two per element (1.63 -> 1.43 ms per 1024 clips, tools/grad_probe.py; the rest is four logf per bin)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long b = i0 / per;
+  const long long r0 = i0 - b * per;
+  int t = (int)(r0 / p.F), k = (int)(r0 - (long long)t * p.F);
+  const long long sb = stride / per;
+  const long long sr = stride - sb * per;
+  const int st = (int)(sr / p.F), sk = (int)(sr - (long long)st * p.F);
+  for (long long i = i0; i < total; i += stride, b += sb, t += st, k += sk) {
+    if (k >= p.F) {
+      k -= p.F;
+      ++t;
+    }
+    if (t >= p.T) {
+      t -= p.T;
+      ++b;
+    }
+    const long long r = (long long)t * p.F + k;
     const float* m = p.mag + b * per;
     const int tu = t + 1 < p.T ? t + 1 : p.T - 1, td = t > 0 ? t - 1 : 0;
     const int kr = k + 1 < p.F ? k + 1 : p.F - 1, kl = k > 0 ? k - 1 : 0;
