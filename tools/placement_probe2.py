@@ -13,7 +13,7 @@ win = stft.window[:1024].contiguous()
 X0 = stft(x[:2])      # initialises the library for this device
 n_el = B * T * F
 slack = 1 << 20     # complex elements of slack behind every candidate (8 MB)
-bufs = [torch.empty(n_el + slack, dtype=torch.complex64, device=dev) for _ in range(4)]
+bufs = [torch.empty(n_el + slack, dtype=torch.complex64, device=dev) for _ in range(int(os.environ.get("PROBE_BUFS", "4")))]
 
 
 def run(p):
