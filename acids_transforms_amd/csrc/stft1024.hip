@@ -1172,7 +1172,8 @@ int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, 
   const long long slots = resident_waves(kernel, 64 * WAVES_PER_BLOCK, 0);
   const long long spr = plan_units_per_run(B, nslots, slots, 8, 1024 / hop - 1);
   p.slots_per_run = spr;
-  p.runs_per_clip = (nslots + spr - 1) / spr;
+  if (const char* e = getenv("ACIDS_ISTFT_SPR")) p.slots_per_run = atoll(e) > 0 ? atoll(e) : spr;   // dev: run length A/B
+  p.runs_per_clip = (nslots + p.slots_per_run - 1) / p.slots_per_run;
   const long long waves = B * p.runs_per_clip;
   const long long blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, p);
