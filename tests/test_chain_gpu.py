@@ -237,3 +237,30 @@ def test_config3_at_full_size(dev):
         assert np.all(np.abs(got - ref_ph) <= tol)
         want = O.polar_istft(m_b.unsqueeze(0), T_(ref_ph).unsqueeze(0), inv_win, 1024, 256)[0]
         assert snr_db(want.numpy(), cpu(y[b])) > 40.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] per GPU at its literal size: 1024 clips -> MFCC(40) and MFCC() (MelSpectrogram), one launch each
+# ---------------------------------------------------------------------------------------------------------------
+def test_config4_compute_at_full_size(dev):
+    """The oracle cannot run 1024 clips x 4 s in seconds, so: (i) clips {0, 511, 1023} of the full-batch result against
+    the oracle run on those clips alone; (ii) the full batch bit-identical to the same clips 128 at a time (the fused
+    feature kernel, the MFMA DCT and the channel-major windows must not depend on where a clip sits in the batch)."""
+    B, L = 1024, 176400
+    gen = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn(B, L, device=dev, generator=gen) * 0.1
+    for kw in ({"n_mfcc": 40}, {}):
+        m = A.MFCC(**kw).to(dev)
+        full = m(x)
+        assert full.shape == (B, 40 if kw else 128, 690)
+        for i in range(0, B, 128):
+            assert torch.equal(full[i:i + 128], m(x[i:i + 128])), (kw, i)
+        pick = [0, 511, 1023]
+        mel = O.melspectrogram(x[pick].cpu(), 44100, 1024, 256, 128, 2.0)                    # (3, 128, T)
+        if kw:
+            db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
+            want = O.mfcc_dct(db.transpose(-1, -2), 40).transpose(-1, -2)
+        else:
+            want = mel
+        assert rel_max(cpu(full[pick]), want.numpy()) < (2e-5 if kw else 1e-5), kw      # the bars of test_mel_gpu.py
+        del full
