@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ACIDS_HIP_LIB") or os.path.join(_HERE, "libacids_hip.so")   # override: kernel A/B experiments
 
-ABI_VERSION = 3            # what this binding was written against (include/acids_hip.h, at_abi_version())
+ABI_VERSION = 4            # what this binding was written against (include/acids_hip.h, at_abi_version())
 
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_i64 = ctypes.c_int64
@@ -25,6 +25,8 @@ _SIGNATURES = {
     "at_abi_version": [],
     "at_error_string": [c_int],
     "at_init": [c_int],
+    "at_set_variant": [c_int, c_int],
+    "at_get_variant": [c_int],
     "at_stft_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_stft_mel_forward": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_int,
                             c_f, c_int, c_int, c_f, c_f, c_flt, c_f, c_f, c_f, c_int, c_f],
@@ -118,6 +120,27 @@ def lib():
                                 % (_SO, L.at_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
+
+
+# kernel variants (include/acids_hip.h AT_VARIANT_*): same results, different kernels; for tests and A/B runs
+VARIANTS = {"epilogue": 0, "frame_kernels": 1, "small_projection": 2, "scan_layout": 3, "pghi_kernel": 4}
+
+
+class variant:
+    """`with variant("epilogue", 1): ...` -- force a kernel variant for the calls inside, restore it afterwards.
+    Process-wide (the table lives in the library), so not for concurrent use from several threads."""
+
+    def __init__(self, name, value):
+        self.which, self.value = VARIANTS[name], int(value)
+
+    def __enter__(self):
+        self.prev = lib().at_get_variant(self.which)
+        check(lib().at_set_variant(self.which, self.value), "at_set_variant")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().at_set_variant(self.which, self.prev), "at_set_variant")
+        return False
 
 
 def exported_symbols():

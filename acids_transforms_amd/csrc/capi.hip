@@ -8,6 +8,8 @@
 #include "band_bank.h"
 #include "fft512.h"
 
+#include <atomic>
+#include "variants.h"
 namespace at_hip {
 // stft1024.hip
 int launch_stft1024_fwd(const float*, long long, long long, long long, long long, int, int, const float*,
@@ -96,6 +98,8 @@ __global__ void envelope_table_kernel(const float* w, int n_fft, int hop, int R,
     }
   env[i] = s;
 }
+static std::atomic<int> g_variants[kVarCount];
+int variant(int which) { return g_variants[which].load(std::memory_order_relaxed); }
 }  // namespace at_hip
 
 using namespace at_hip;
@@ -104,7 +108,19 @@ extern "C" {
 
 // 2: at_sinebank_realtime takes the synthesis window; bf16 projection, at_oadd_push
 // 3: any n_fft (odd sizes give torch.istft's hop (T-1) + 1 samples); Cartesian pack / unpack; strided phase scans
-int at_abi_version(void) { return 3; }
+// 4: at_set_variant / at_get_variant (round 4; the library no longer reads environment variables)
+int at_abi_version(void) { return 4; }
+
+int at_set_variant(int which, int value) {
+  if (which < 0 || which >= kVarCount || value < 0 || value > 2) return AT_EINVAL;
+  g_variants[which].store(value, std::memory_order_relaxed);
+  return AT_OK;
+}
+
+int at_get_variant(int which) {
+  if (which < 0 || which >= kVarCount) return AT_EINVAL;
+  return g_variants[which].load(std::memory_order_relaxed);
+}
 
 const char* at_error_string(int code) {
   switch (code) {
@@ -140,9 +156,11 @@ int at_init(int device) {
     }
   float2* d = nullptr;
   int rc = AT_OK;
-  if (hipMalloc((void**)&d, sizeof(float2) * kTwiddleCount) != hipSuccess) rc = AT_ELAUNCH;
+  // the table, then the tile-counter ring of the persistent forward kernels (stft1024.hip: tile_counter_slot), zeroed
+  if (hipMalloc((void**)&d, sizeof(float2) * (kTwiddleCount + kTileCtrSlots)) != hipSuccess) rc = AT_ELAUNCH;
   if (rc == AT_OK && hipMemcpy(d, tab.data(), sizeof(float2) * kTwiddleCount, hipMemcpyHostToDevice) != hipSuccess)
     rc = AT_ELAUNCH;
+  if (rc == AT_OK && hipMemset(d + kTwiddleCount, 0, sizeof(float2) * kTileCtrSlots) != hipSuccess) rc = AT_ELAUNCH;
   float2* d2 = nullptr;
   if (rc == AT_OK) {
     // [0, 1024): W2048^k; [1024, 1280): W512^k; [1280, 1664): W512^(r k), r = 1..3, k < 128 (n_fft 256);

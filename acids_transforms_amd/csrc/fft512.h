@@ -29,6 +29,7 @@ constexpr int kFftLdsFloat2PerWave = 568;  // 7*72 + 63 + 1
 //   [7*64   .. 14*64)  tw2[k1-1][lane]  = W64^{(lane&7)*k1}       k1 = 1..7
 //   [14*64  .. 22*64)  twr[m][lane]     = W1024^{lane + 64 m}     m  = 0..7
 constexpr int kTwiddleCount = 22 * 64;
+constexpr int kTileCtrSlots = 4096;   // {next tile, workgroups done} pairs behind the twiddle table (persistent kernels)
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
@@ -254,6 +255,25 @@ __device__ __forceinline__ void fft512(v2f (&v)[8], const TW& tw, float2* lds_f2
   wave_lds_sync();
   radix8<INV>(v);
 }
+// The fixed-length mel epilogues (stft1024.hip, FQ path) lay |X| over this slab as 513 floats and let a walk run on to
+// float 639 over zero weights WITHOUT clearing floats 513..639 first: correct only while those floats -- float2 slots
+// 256..319 -- hold finite leftovers of the SAME frame, i.e. while the two exchanges above rewrite every one of them in
+// every transform (0 x Inf would be NaN, stale values of an earlier frame might be anything).  Pinned here, next to the
+// strides it depends on.
+constexpr bool fft512_exchanges_cover(int lo_slot, int hi_slot) {
+  for (int s = lo_slot; s <= hi_slot; ++s) {
+    bool hit = false;
+    for (int a = 0; a < 8 && !hit; ++a) {
+      if (s >= a * 72 && s < a * 72 + 64) hit = true;     // xchg 1: hi * 72 + lo + 8 k
+      if (s >= a * 66 && s < a * 66 + 64) hit = true;     // xchg 2: lo * 66 + hi + 8 k
+    }
+    if (!hit) return false;
+  }
+  return true;
+}
+static_assert(fft512_exchanges_cover(256, 319) && 320 <= kFftLdsFloat2PerWave,
+              "the fixed-length mel epilogue reads absrow[513..639] uncleared: both exchanges must rewrite float2 slots 256..319");
+
 template <bool INV, typename TW>
 __device__ __forceinline__ void fft512(float2 (&f)[8], const TW& tw, float2* lds, int lane) {
   v2f v[8];

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "mel_gemm.h"   // A_* / C_* codes
+#include "variants.h"
 
 namespace at_hip {
 
@@ -564,7 +565,7 @@ int at_mel_project_banded(const void* A, int a_kind, int64_t rows, int64_t lda, 
   // the headline projection in its fixed form: |X| of 513-bin rows, log1p, two passes of 8 and 2 quads, row-major
   if (a_kind == A_COMPLEX_ABS && !inverse && contrast == C_LOG1P && K == 513 && lda == 513 && ld_out == n_filters &&
       T_transposed == 0 && !phase_out && !phase_in && n_passes == 2 && pass_len_host[0] == 32 && pass_len_host[1] == 8 &&
-      (((uintptr_t)A) & 7) == 0 && !getenv("ACIDS_GENERIC_EPILOGUE"))
+      (((uintptr_t)A) & 7) == 0 && variant(kVarEpilogue) == 0)
     return launch_fixed_proj(p, s);
   return a_kind >= A_REAL ? launch_banded<false>(p, dyn_lds, s) : launch_banded<true>(p, dyn_lds, s);
 }
@@ -847,9 +848,9 @@ extern "C" int at_project_small(const float* x, int64_t rows, int K, const float
   if (K > 128 || N > 64) return AT_EUNSUPPORTED;
   SmallProjParams p = {x, W, out, offset, scale, rows, T_transposed, 0, K, N};
   hipStream_t s = (hipStream_t)stream;
-  if ((K == 128 || K == 80 || K == 64) && (((uintptr_t)x) & 15) == 0 && !getenv("ACIDS_PROJECT_SMALL_VALU")) {
+  if ((K == 128 || K == 80 || K == 64) && (((uintptr_t)x) & 15) == 0 && variant(kVarSmallProjection) == 0) {
     // matrix-core form: every wave a whole number of 32-row tile pairs
-    const char* form = getenv("ACIDS_PROJECT_SMALL_FORM");      // dev switch: "regs", "regs_nt", "lds", "lds_nt"
+    const char* form = dev_env("ACIDS_PROJECT_SMALL_FORM");     // dev builds: "regs", "regs_nt", "lds", "lds_nt"
     const int f = !form ? 2 : !strcmp(form, "regs") ? 0 : !strcmp(form, "regs_nt") ? 1 : !strcmp(form, "lds") ? 2 : 3;
     const long long waves_target = (long long)num_cus() * (f >= 2 ? 16 : 8);
     long long rpw = (rows + waves_target - 1) / waves_target;

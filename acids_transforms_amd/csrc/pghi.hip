@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "../../include/acids_hip.h"
+#include "variants.h"
 
 namespace at_hip {
 
@@ -1651,7 +1652,7 @@ static int pghi_integrate_launch(float* spec, const float* tg, const float* fg, 
                                  float* phase, at_hip::HeapItem* heap, int64_t* npops_or_null, int32_t* order_or_null,
                                  hipStream_t s) {
   using namespace at_hip;
-  static const int prof = [] { const char* e = getenv("ACIDS_PGHI_PROF"); return (e && e[0] == '1') ? 1 : 0; }();
+  static const int prof = [] { const char* e = dev_env("ACIDS_PGHI_PROF"); return (e && e[0] == '1') ? 1 : 0; }();   // dev builds only
   // LDS share of the heap: as much as fits while every clip of the batch can still be resident (160 KB per CU)
   int cus = 256;
   {
@@ -1668,11 +1669,12 @@ static int pghi_integrate_launch(float* spec, const float* tg, const float* fg, 
   const size_t heap_lds = sizeof(u64) * ((size_t)(cap + 1) + (size_t)(seg_cap + 1) / 2);
   HgiParams h = {spec, tg, fg, phase, heap, (long long)B, T, F, abstol, tol, (long long*)npops_or_null, cap, seg_cap, prof,
                  order_or_null};
-  // ACIDS_PGHI_SERIAL=1 selects the single-lane reference kernel (debugging aid; identical results)
-  static const bool serial = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
-  // ACIDS_PGHI_KERNEL=wbit selects the winner-bit variant (identical results; slower on every batch measured, see the
-  // comment above it and DESIGN.md 3.4 -- kept selectable so that the parity tests and tools/fuzz_pghi.py can run it)
-  static const bool use_coop = [] { const char* e = getenv("ACIDS_PGHI_KERNEL"); return !(e && e[0] == 'w'); }();
+  // at_set_variant(AT_VARIANT_PGHI_KERNEL, 2) selects the single-lane reference kernel (debugging aid; identical results),
+  // 1 the winner-bit variant (identical results; slower on every batch measured, see the comment above it and DESIGN.md
+  // 3.4 -- kept selectable so that the parity tests and tools/fuzz_pghi.py can run it)
+  const int pghi_kernel = variant(kVarPghiKernel);
+  const bool serial = pghi_kernel == 2;
+  const bool use_coop = pghi_kernel != 1;
   if (serial) {
     hipLaunchKernelGGL(pghi_hgi_offline_kernel, dim3((unsigned)B), dim3(64), 0, s, h);
   } else if (!use_coop && !prof) {
@@ -1692,7 +1694,7 @@ static int pghi_integrate_launch(float* spec, const float* tg, const float* fg, 
     hipLaunchKernelGGL(pghi_hgi_offline_wbit_kernel, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(64 * wpb), block_lds, s, h);
   } else {
     void (*kernel)(HgiParams) = prof ? pghi_hgi_offline_coop_kernel<true> : pghi_hgi_offline_coop_kernel<false>;
-    if (const char* e = getenv("ACIDS_PGHI_PUSH"))        // dev A/B: "batch" = the parent pre-test of the pushes (slower)
+    if (const char* e = dev_env("ACIDS_PGHI_PUSH"))       // dev builds: "batch" = the parent pre-test of the pushes (slower)
       if (!strcmp(e, "batch")) kernel = prof ? pghi_hgi_offline_coop_kernel<true, true> : pghi_hgi_offline_coop_kernel<false, true>;
     // waves per workgroup: as many (<= 8) as keep the workgroup's heap tops within the CU's 160 KB
     int wpb = per_cu >= 8 ? 8 : per_cu >= 4 ? 4 : per_cu >= 2 ? 2 : 1;
@@ -1742,8 +1744,8 @@ static int pghi_realtime_impl(const float* mag_hist, const float* mag, const flo
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pghi_grad_rt_kernel, dim3(grid1d((long long)S * per)), dim3(256), 0, s, p);
   const size_t lds = sizeof(float) * (7 * (size_t)F + 1) + sizeof(HeapItem) * (4 * (size_t)F + 8);
-  // ACIDS_PGHI_SERIAL=1 selects the single-lane kernels (debugging aid; identical results)
-  static const bool serial_rt = [] { const char* e = getenv("ACIDS_PGHI_SERIAL"); return e && e[0] == '1'; }();
+  // at_set_variant(AT_VARIANT_PGHI_KERNEL, 2) selects the single-lane kernels (debugging aid; identical results)
+  const bool serial_rt = variant(kVarPghiKernel) == 2;
   if (lds <= 64 * 1024 && !serial_rt) {
     const size_t per_wave = (lds + 15) & ~(size_t)15;
     // up to one stream per CU spreads best (256 streams: 3.5 ms alone on their CUs, 3.7 ms packed four to a CU);

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "../../include/acids_hip.h"
+#include "variants.h"
 
 namespace at_hip {
 
@@ -87,12 +88,14 @@ __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_scan_kernel(ScanPar
   } else {
     b = blockIdx.x;
     const long long H = (F + NC - 1) / NC;
-    if ((long long)threadIdx.x >= H) return;
+    // the block is H rounded up to whole wavefronts: the surplus threads stay alive (every thread of the block must
+    // reach the barriers of the row loop), walk column 0 and store nothing
+    const bool live = (long long)threadIdx.x < H;
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       const long long f = threadIdx.x + k * H;
-      on[k] = f < F;
-      fk[k] = on[k] ? f : (long long)threadIdx.x;     // a column past the end walks column j again and stores nothing
+      on[k] = live && f < F;
+      fk[k] = on[k] ? f : (live ? (long long)threadIdx.x : 0);     // a column past the end walks a valid column again and stores nothing
     }
   }
   float off = 0.f, sc = 1.f;
@@ -252,12 +255,12 @@ __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_integrate_kernel(In
   } else {
     b = blockIdx.x;
     const long long H = (F + NC - 1) / NC;
-    if ((long long)threadIdx.x >= H) return;
+    const bool live = (long long)threadIdx.x < H;       // surplus threads stay for the barriers, see phase_scan_kernel
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       const long long f = threadIdx.x + k * H;
-      on[k] = f < F;
-      fk[k] = on[k] ? f : (long long)threadIdx.x;
+      on[k] = live && f < F;
+      fk[k] = on[k] ? f : (live ? (long long)threadIdx.x : 0);
     }
   }
   const long long f = fk[0];
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void polar_to_complex_kernel(const float* __re
 // columns per thread of the clip-per-block layout (0: flattened columns): rows that are not a whole number of 64-byte
 // segments, long enough for a block of their own, short enough for 1024 threads x 4
 static int clip_block_columns(long long F, long long B, int elem_bytes) {
-  if (getenv("ACIDS_SCAN_FLAT")) return 0;
+  if (variant(kVarScanLayout) == 1) return 0;
   if ((F * elem_bytes) % 64 == 0 || F < 256 || B < 64) return 0;
   return F <= 2048 ? 2 : F <= 4096 ? 4 : 0;
 }

@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "../../include/acids_hip.h"
+#include "variants.h"
 
 namespace at_hip {
 
@@ -371,7 +372,7 @@ int at_cartesian_pack(const float* x_complex, int64_t rows, int F, const float* 
   const long long n = (long long)rows * F;
   const unsigned grid = grid_for(n, 256) * 4;      // grid_for caps at 8 blocks per CU: one element per thread and trip here
   if ((F * 4) % 64 != 0 && F >= 64 && rows >= 64 && (rows + kPackRows - 1) / kPackRows < (1LL << 31) &&
-      !getenv("ACIDS_CARTESIAN_FLAT")) {
+      !dev_env("ACIDS_CARTESIAN_FLAT")) {
     hipLaunchKernelGGL(cartesian_pack_rows_kernel, dim3((unsigned)((rows + kPackRows - 1) / kPackRows)), dim3(256), 0,
                        (hipStream_t)stream, (const float2*)x_complex, (long long)rows, F, re_offset, re_scale, im_offset,
                        im_scale, stacked);

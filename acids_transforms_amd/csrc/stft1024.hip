@@ -19,10 +19,12 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 
 #include "band_bank.h"
 #include "fft512.h"
 #include "run_plan.h"
+#include "variants.h"
 
 #ifndef AT_ISTFT_NT
 #define AT_ISTFT_NT 1
@@ -166,6 +168,9 @@ struct FwdRunParams {
   long long feat_ld, phase_ld;   // row strides (0: n_filters / F)
   const float* ph_offset;        // Normalize affine of the phase half (device scalars or null)
   const float* ph_scale;
+  // PW (persistent workgroups): tiles of FWD_WAVES consecutive runs are handed out in address order
+  unsigned* tile_ctr;            // {next tile, workgroups done}: zero before the launch, reset by the last workgroup
+  unsigned n_tiles;
 };
 
 // element n = lane + 64 m of the frame starting at padded position p0 (original index p0 - 512 + 2n)
@@ -213,7 +218,7 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) { re
 // NT: those stores non-temporal.  tools/ubench/stream_pattern2.hip prices the pattern: rows 4.7 TB/s, aligned blocks
 // 4.95, aligned + nt 5.0-5.3 (profiles/r03a_*).
 template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2, int SP = 0,
-          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false, int HYB = 0, int FC = 1, bool FP2 = false>
+          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false, int HYB = 0, int FC = 1, bool FP2 = false, bool PW = false>
 __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
   // HYB (with TWLDS): bit 0 -- the two pass twiddle tables in registers, only the merge's W1024 rows from LDS
   // (HybridTwiddles); bit 1 -- the analysis window in registers.  Both trade LDS reads (the busiest unit of these
@@ -247,16 +252,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
       lane_tab[64 * p.bank.n_passes + i] = p.bank.lane_filter[i];
     }
   }
+  // PW: the workgroup stays resident and takes TILES -- FWD_WAVES consecutive runs, one per wave -- in address order from
+  // a device counter (one returning atomic per workgroup and tile, requested one tile ahead), with a workgroup barrier
+  // per tile.  Short runs (8 frames) then cost neither a workgroup launch nor an LDS table refill, and the chip writes
+  // ONE advancing window of ~4096 short runs instead of 4096 fronts a run length apart: the access-pattern ceiling of
+  // the fused forward rises from 5.06 to 5.6-5.8 TB/s (tools/ubench/stream_pattern3.hip, shapes P / D / Pw;
+  // profiles/r04_launch_shape.md).
+  __shared__ unsigned s_tile[2];
+  if (PW && threadIdx.x == 0) s_tile[0] = atomicAdd(p.tile_ctr, 1u);
   __syncthreads();
-
-  const long long run = (long long)blockIdx.x * FWD_WAVES + wave;
-  const long long b = run / p.runs_per_clip;
-  if (b >= p.B) return;
-  const long long r = run - b * p.runs_per_clip;
-  const long long t0 = r * p.frames_per_run;
-  long long t1 = t0 + p.frames_per_run;
-  if (t1 > p.T) t1 = p.T;
-  if (t0 >= t1) return;
 
   int sp_f[SP > 0 ? SP : 1], sp_start[SP > 0 ? SP : 1], sp_quads[SP > 0 ? SP : 1];
   if constexpr (SP > 0) {
@@ -287,10 +291,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
     for (int m = 0; m < 8; ++m) win_regs[m] = to_v(reinterpret_cast<const float2*>(p.window)[lane + 64 * m]);
   }
 
-  const float* clip = p.x + b * p.clip_stride;
-  const bool clip_aligned = ((((uintptr_t)clip) & 7) == 0);  // frame starts are multiples of 256 samples
   const long long L = p.L;
   const int lane2 = 2 * lane;
+
+  auto do_run = [&](const long long run) {
+  const long long b = run / p.runs_per_clip;
+  if (b >= p.B) return;
+  const long long r = run - b * p.runs_per_clip;
+  const long long t0 = r * p.frames_per_run;
+  long long t1 = t0 + p.frames_per_run;
+  if (t1 > p.T) t1 = p.T;
+  if (t0 >= t1) return;
+  const float* clip = p.x + b * p.clip_stride;
+  const bool clip_aligned = ((((uintptr_t)clip) & 7) == 0);  // frame starts are multiples of 256 samples
 
   // first frame of the run: all eight segments
   float2 raw[8];
@@ -622,6 +635,28 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   flush_nyquist();
   if constexpr (AL) {
     if (lane < rot) put(sp, carry);      // the run's last block: the next run (or clip) owns the rest of it
+  }
+  };   // do_run
+
+  if constexpr (!PW) {
+    do_run((long long)blockIdx.x * FWD_WAVES + wave);
+  } else {
+    for (int it = 0;; ++it) {
+      const unsigned tile = __builtin_amdgcn_readfirstlane(s_tile[it & 1]);
+      if (tile >= p.n_tiles) break;
+      unsigned nxt = 0;
+      if (threadIdx.x == 0) nxt = atomicAdd(p.tile_ctr, 1u);       // consumed after this tile's run
+      do_run((long long)tile * FWD_WAVES + wave);
+      if (threadIdx.x == 0) s_tile[(it + 1) & 1] = nxt;
+      __syncthreads();
+    }
+    // the last workgroup to leave re-arms the counter pair for the next launch that is given this slot
+    if (threadIdx.x == 0) {
+      if (atomicAdd(p.tile_ctr + 1, 1u) == gridDim.x - 1) {
+        atomicExch(p.tile_ctr, 0u);
+        atomicExch(p.tile_ctr + 1, 0u);
+      }
+    }
   }
 }
 
@@ -992,6 +1027,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void irfft1024_frames_kernel(
 // ---------------------------------------------------------------------------
 namespace at_hip {
 
+// Counter pairs of the persistent kernels live behind the device's twiddle table (capi.hip: at_init allocates
+// kTwiddleCount float2 + kTileCtrSlots pairs, zeroed).  Every launch takes the next pair of the ring; a kernel leaves
+// its pair zeroed, so a pair is only ever in doubt if kTileCtrSlots launches are issued while one is still pending on
+// another stream.
+unsigned* tile_counter_slot(const float2* tw) {
+  static std::atomic<unsigned> cursor{0};
+  const unsigned slot = cursor.fetch_add(1, std::memory_order_relaxed) % kTileCtrSlots;
+  return reinterpret_cast<unsigned*>(const_cast<float2*>(tw) + kTwiddleCount) + 2 * slot;
+}
+
 int launch_stft1024_fwd(const float* x, long long B, long long L, long long clip_stride, long long T, int hop,
                         int center, const float* window, const float2* tw, float2* out, float* phase,
                         hipStream_t stream) {
@@ -1046,6 +1091,7 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   // cover the epilogue's LDS round trips (4 % faster than the 3-wave form, A/B on one device).
   int NW = 4;
   bool fq_logpow = false;
+  bool persistent = false;
   void (*kernel)(FwdRunParams) = nullptr;
   if (!bank) {
     if (hop == 128)
@@ -1071,19 +1117,19 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     // ... and with the walk lengths of the headline bank (128 mel filters at 44.1 kHz: 8 + 2 quads), log1p and |X|:
     // the fixed-length epilogue
     if (hop == 256 && !polar && !phase && !feat_channel_major && bank->n_passes == 2 && contrast == 1 && !power2 &&
-        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && !getenv("ACIDS_GENERIC_EPILOGUE"))
+        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && variant(kVarEpilogue) == 0)
       kernel = out ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>
                    : stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 2, 8, 2>;
     // the log-mel of BASELINE configs[3] (log contrast, |X|^2, features only) on the same fixed-length epilogue
     if (hop == 256 && !polar && !phase && !feat_channel_major && !out && bank->n_passes == 2 && contrast == 2 && power2 &&
-        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && !getenv("ACIDS_GENERIC_EPILOGUE")) {
+        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && variant(kVarEpilogue) == 0) {
       kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 0, false, 2, 2, 8, 2, false, false, 3, 2, true>;
       fq_logpow = true;
     }
     // MelSpectrogram (the reference's MFCC: |X|^2 on the 128-filter bank, no contrast, channel-major (.., N, T) output,
     // spectrum never stored) on the same fixed-length epilogue, its two results parked in the register windows
     if (hop == 256 && !polar && !phase && feat_channel_major && !out && bank->n_passes == 2 && contrast == 0 && power2 &&
-        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && !getenv("ACIDS_GENERIC_EPILOGUE")) {
+        bank->pass_len[0] == 32 && bank->pass_len[1] == 8 && variant(kVarEpilogue) == 0) {
       // 4-wave blocks at three waves per SIMD (142 registers); with the pass twiddles in registers as well (HYB = 3) the
       // two windows no longer fit and spill (0.75 ms against 0.72; the run-time-length epilogue: 0.755)
       kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 2, false, 2, 2, 8, 2, false, false, 0, 0, true>;
@@ -1105,18 +1151,29 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   // the fixed-length fused epilogue.  ACIDS_FWD_STORES = rows | aligned | aligned_nt picks the form for A/B runs.
   {
     static const int store_mode = [] {
-      const char* e = getenv("ACIDS_FWD_STORES");
+      const char* e = dev_env("ACIDS_FWD_STORES");        // dev builds only
       if (!e) return 2;
       return !strcmp(e, "rows") ? 0 : !strcmp(e, "aligned") ? 1 : 2;
     }();
     const bool al_ok = store_mode != 0 && hop == 256 && out && !phase && !polar && (((uintptr_t)out) & 511) == 0;
+    // persistent workgroups (PW): measured slower than one long run per wave on the product kernels
+    // (profiles/r04_launch_shape.md); a development variant
+    static const bool pw_mode = [] { const char* e = dev_env("ACIDS_FWD_PW"); return e && e[0] == '1'; }();
     if (al_ok && !bank) {
       NW = 8;
       kernel = store_mode == 1 ? stft1024_h256_fwd_kernel<false, 0, 8, true, 0, false, 2, 0, 0, 0, true, false>
                                : stft1024_h256_fwd_kernel<false, 0, 8, true, 0, false, 2, 0, 0, 0, true, true>;
+      if (store_mode == 2 && pw_mode) {
+        kernel = stft1024_h256_fwd_kernel<false, 0, 8, true, 0, false, 2, 0, 0, 0, true, true, 0, 1, false, true>;
+        persistent = true;
+      }
     } else if (al_ok && kernel == (void (*)(FwdRunParams))stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>) {
       kernel = store_mode == 1 ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, false>
                                : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, true>;
+      if (store_mode == 2 && pw_mode) {
+        kernel = stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, true, 0, 1, false, true>;
+        persistent = true;
+      }
     }
     // Features only (the spectrum never stored) is bound by the LDS and by instruction issue, not by HBM: with both
     // pass-twiddle tables and the window in registers (HYB = 3: 30 fewer LDS reads per frame) at three waves per SIMD --
@@ -1125,7 +1182,7 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     // / 0.866 / 0.869 ms, plain 0.756 / 0.758 / 0.779): their waves wait on store issue, and the plain one loses its
     // fifth and sixth wave.  5 waves per SIMD (10-wave blocks, 96 registers, 2 spilled): 0.65 -> 0.69 ms.
     if (kernel == (void (*)(FwdRunParams))stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 2, 8, 2> &&
-        !getenv("ACIDS_FWD_NOHYB")) {
+        !dev_env("ACIDS_FWD_NOHYB")) {
       NW = 4;
       kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 0, false, 2, 2, 8, 2, false, false, 3>;
     }
@@ -1134,16 +1191,34 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
   const long long fpr = plan_units_per_run(B, T, slots, 8, hop == 128 ? 5 : 1);
   p.frames_per_run = fpr;
-  if (const char* e = getenv("ACIDS_FWD_FPR")) p.frames_per_run = atoll(e) > 0 ? atoll(e) : fpr;   // dev: run length A/B
+  if (const char* e = dev_env("ACIDS_FWD_FPR")) {     // dev builds: run length A/B, clamped to what the kernels assume
+    const long long v = atoll(e);
+    if (v >= 8 && v <= T) p.frames_per_run = v;
+  }
   p.runs_per_clip = (T + p.frames_per_run - 1) / p.frames_per_run;
   const long long waves = B * p.runs_per_clip;
-  if (getenv("ACIDS_DEBUG_PLAN")) {
+  if (dev_env("ACIDS_DEBUG_PLAN")) {
     hipFuncAttributes fa = {};
     (void)hipFuncGetAttributes(&fa, (const void*)kernel);
     fprintf(stderr, "[plan fwd] NW %d slots %lld (regs %d, static lds %zu, dyn %zu) frames/run %lld runs/clip %lld waves %lld\n", NW,
             slots, fa.numRegs, fa.sharedSizeBytes, dyn_lds, p.frames_per_run, p.runs_per_clip, waves);
   }
-  hipLaunchKernelGGL(kernel, dim3((unsigned)((waves + NW - 1) / NW)), dim3(64 * NW), dyn_lds, stream, p);
+  long long blocks = (waves + NW - 1) / NW;
+  if (persistent) {
+    // short runs (the planner's figure is one long run per resident wave), tiles of NW runs, as many workgroups as fit
+    long long g = 8;
+    if (const char* e = dev_env("ACIDS_FWD_PW_RUN")) g = atoll(e) >= 2 ? atoll(e) : 8;
+    if (g > T) g = T;
+    p.frames_per_run = g;
+    p.runs_per_clip = (T + g - 1) / g;
+    const long long tiles = (B * p.runs_per_clip + NW - 1) / NW;
+    if (tiles >= (1LL << 31)) return -1;
+    p.n_tiles = (unsigned)tiles;
+    p.tile_ctr = tile_counter_slot(tw);
+    blocks = slots / NW;
+    if (blocks > tiles) blocks = tiles;
+  }
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * NW), dyn_lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -1172,7 +1247,10 @@ int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, 
   const long long slots = resident_waves(kernel, 64 * WAVES_PER_BLOCK, 0);
   const long long spr = plan_units_per_run(B, nslots, slots, 8, 1024 / hop - 1);
   p.slots_per_run = spr;
-  if (const char* e = getenv("ACIDS_ISTFT_SPR")) p.slots_per_run = atoll(e) > 0 ? atoll(e) : spr;   // dev: run length A/B
+  if (const char* e = dev_env("ACIDS_ISTFT_SPR")) {   // dev builds: run length A/B
+    const long long v = atoll(e);
+    if (v >= 8 && v <= nslots) p.slots_per_run = v;
+  }
   p.runs_per_clip = (nslots + p.slots_per_run - 1) / p.slots_per_run;
   const long long waves = B * p.runs_per_clip;
   const long long blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;

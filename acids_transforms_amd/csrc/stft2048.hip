@@ -26,6 +26,7 @@
 #include "band_bank.h"
 #include "mel_gemm.h"   // C_* contrast codes
 #include "run_plan.h"
+#include "variants.h"
 #include <stdlib.h>
 
 namespace at_hip {
@@ -900,7 +901,7 @@ int launch_stft2048_fwd(const float* x, long long B, long long L, long long clip
   // the sliding-window / aligned-stream kernel: torch.stft's framing at hop n/4, 16-byte aligned clips, a 512-byte
   // aligned output (torch allocations are), no phase side output
   if (center && hop == 512 && !phase && L >= 2048 && (clip_stride & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
-      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 15) == 0 && !getenv("ACIDS_STFT2048_FRAMES")) {
+      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 15) == 0 && variant(kVarFrameKernels) == 0) {
     P2kRun q = {};
     q.x = x; q.window = window; q.tw = tw; q.tw2k = tw2k; q.X = out;
     q.B = B; q.L = L; q.clip_stride = clip_stride; q.T = T;

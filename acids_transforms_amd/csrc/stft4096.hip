@@ -23,6 +23,7 @@
 #include "fastmath.h"
 #include "fft512.h"
 #include "run_plan.h"
+#include "variants.h"
 #include <stdlib.h>
 
 namespace at_hip {
@@ -639,7 +640,7 @@ int launch_stft4096_fwd(const float* x, long long B, long long L, long long clip
   // the sliding-window / aligned-stream kernel: torch.stft's framing at hop n/4, 16-byte aligned clips, a 512-byte
   // aligned output, no phase side output
   if (center && hop == 1024 && !phase && L >= 4096 && (clip_stride & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
-      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 15) == 0 && !getenv("ACIDS_STFT4096_FRAMES")) {
+      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 15) == 0 && variant(kVarFrameKernels) == 0) {
     P4kRun q = {};
     q.x = x; q.window = window; q.tw = tw; q.tw4k = tw4k; q.X = out;
     q.B = B; q.L = L; q.clip_stride = clip_stride; q.T = T;

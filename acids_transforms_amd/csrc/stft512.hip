@@ -22,6 +22,7 @@
 #include "band_bank.h"
 #include "mel_gemm.h"   // C_* contrast codes
 #include "run_plan.h"
+#include "variants.h"
 #include <stdlib.h>
 
 namespace at_hip {
@@ -917,7 +918,7 @@ int launch_stft512_fwd(const float* x, long long B, long long L, long long clip_
   // the sliding-window / aligned-stream kernel: torch.stft's framing at hop n/4, 8-byte aligned clips, a 512-byte aligned
   // output, no phase side output
   if (center && hop == 128 && !phase && L >= 512 && (clip_stride & 1) == 0 && (((uintptr_t)x) & 7) == 0 &&
-      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 7) == 0 && !getenv("ACIDS_STFT512_FRAMES")) {
+      (((uintptr_t)out) & 511) == 0 && (((uintptr_t)window) & 7) == 0 && variant(kVarFrameKernels) == 0) {
     P5Run q = {};
     q.x = x; q.window = window; q.tw = tw; q.tw512 = tw512; q.X = out;
     q.B = B; q.L = L; q.clip_stride = clip_stride; q.T = T;

@@ -67,24 +67,31 @@ def _free_port():
     return port
 
 
-def visible_gpu_count() -> int:
-    """GPUs this process could open, counted WITHOUT any HIP / torch call: KFD topology nodes that have SIMDs and whose
-    render node is accessible, cut down by ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES the way the runtime applies them (a
-    list of indices or UUIDs; the list ends at the first negative entry).  An over-count is harmless: a rank whose device
-    does not exist fails on its own (`no ROCm device` / `LOCAL_RANK ... not visible`, exit 3) and the parent relays it."""
+def visible_gpu_census():
+    """(count, definite): GPUs this process could open, counted WITHOUT any HIP / torch call: KFD topology nodes that have
+    SIMDs and whose render node is accessible, cut down by ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES the way the runtime
+    applies them (a list of indices or UUIDs; the list ends at the first negative entry).  An over-count is harmless: a
+    rank whose device does not exist fails on its own (`no ROCm device` / `LOCAL_RANK ... not visible`, exit 3) and the
+    parent relays it.  An UNDER-count would refuse a valid job, so the count is only `definite` when it rests on
+    something this function could actually read: a visibility mask, or a KFD topology with at least one readable GPU
+    node (a missing / masked /sys/class/kfd, or zero nodes while /dev/kfd exists, is "unknown", not "none")."""
     import glob
     n = 0
+    readable = 0
     for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
         try:
             kv = dict(line.split(None, 1) for line in open(prop).read().splitlines() if " " in line)
         except OSError:
             continue
+        readable += 1
         if int(kv.get("simd_count", "0")) <= 0:
             continue                                           # a CPU node
         minor = int(kv.get("drm_render_minor", "-1"))
         if minor >= 0 and not os.access("/dev/dri/renderD%d" % minor, os.R_OK | os.W_OK):
             continue                                           # not handed to this container
         n += 1
+    definite = readable > 0 and (n > 0 or not os.path.exists("/dev/kfd"))
+    masked = None
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         val = os.environ.get(var)
         if val is None:
@@ -95,15 +102,23 @@ def visible_gpu_count() -> int:
             if not item or item.startswith("-"):
                 break
             listed += 1
-        n = min(n, listed)
-    return n
+        masked = listed if masked is None else min(masked, listed)
+    if masked is not None:
+        # a mask is an upper bound whatever the topology says (HIP indices are relative to ROCR's list: min() of the
+        # list lengths can only over-count)
+        return (min(n, masked) if definite else masked), True
+    return n, definite
+
+
+def visible_gpu_count() -> int:
+    return visible_gpu_census()[0]
 
 
 def launch_ranks(args) -> int:
     n = args.gpus
     rehearsal = os.environ.get("ACIDS_BENCH_REHEARSAL") == "1"
-    ndev = visible_gpu_count()                # sysfs only: the parent neither imports torch nor touches HIP
-    if not rehearsal and ndev < n:
+    ndev, definite = visible_gpu_census()     # sysfs only: the parent neither imports torch nor touches HIP
+    if not rehearsal and definite and ndev < n:
         print(json.dumps({"error": "--gpus %d asked for, %d ROCm device(s) visible: refusing to report a smaller "
                                    "job under that name" % (n, ndev), "n_gpus_visible": ndev}))
         return 3
@@ -302,6 +317,41 @@ REFERENCE_COMPOSITE = {
 
 
 # ----------------------------------------------------------------------------------------------
+# what the exit status says (pure functions: tests/test_bench_cpu.py feeds them result dictionaries)
+# ----------------------------------------------------------------------------------------------
+def verification_failures(result):
+    """Paths of every `*spot_check` entry of the result whose `ok` is not true: the bench checks what its timed calls
+    produced against the oracle (parity_spot_check, pghi_invert.*_spot_check), and a number on unverified output must
+    not leave with status 0."""
+    bad = []
+
+    def walk(node, path):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                here = path + [str(k)]
+                if str(k).endswith("spot_check") and isinstance(v, dict) and v.get("ok") is not True:
+                    bad.append(".".join(here))
+                walk(v, here)
+
+    walk(result, [])
+    return sorted(bad)
+
+
+def exit_status(result):
+    """0: every figure measured and verified.  5: a spot check of a timed result failed (takes precedence: the headline
+    itself is in doubt).  4: a side measurement raised (`*_error` key); the line is complete either way."""
+    if verification_failures(result):
+        return 5
+    if any(str(k).endswith("_error") for k in result):
+        return 4
+    return 0
+
+
+class LegFailed(RuntimeError):
+    """A measurement leg that holds collectives failed on some rank; raised on EVERY rank (see all_ok)."""
+
+
+# ----------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -342,10 +392,14 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
+            # an explicit timeout: a rank that dies (or never issues its half of a collective) turns into an error on
+            # the others after this long instead of a hang -- the parent / torchrun then ends the job non-zero
+            import datetime
+            limit = datetime.timedelta(seconds=int(os.environ.get("ACIDS_BENCH_DIST_TIMEOUT", "180")))
             if rehearsal:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=limit)
             else:
-                dist.init_process_group("nccl", device_id=dev)
+                dist.init_process_group("nccl", device_id=dev, timeout=limit)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -372,9 +426,24 @@ def main():
     fused = (not args.unfused) and mag.can_fuse_with(stft, x)
     config4 = args.pipeline == "config4"
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
+    # dev only: ACIDS_BENCH_INJECT_FAILURE="<rank>:<leg>" makes that rank raise inside that leg ("step" | "config4"):
+    # the rehearsal test of the N > 1 control flow (tests/test_bench_gpu.py)
+    inject = os.environ.get("ACIDS_BENCH_INJECT_FAILURE", "")
+    inject_rank, inject_leg = (int(inject.split(":")[0]), inject.split(":")[1]) if ":" in inject else (-1, "")
+
+    def maybe_fail(leg):
+        if rank == inject_rank and leg == inject_leg:
+            raise RuntimeError("injected failure on rank %d in leg %s" % (rank, leg))
+
+    def all_ok(ok=True):
+        """The barrier of every leg that holds collectives, carrying each rank's verdict: an all-reduce(MIN) of `ok`.
+        A rank whose share of a leg raised still arrives here, so the others are never left inside a collective; if any
+        rank failed, every rank learns it at the same point and leaves the leg together (LegFailed on all of them)."""
+        if not use_dist:
+            return ok
+        tt = torch.tensor([1 if ok else 0], device=red_dev, dtype=torch.int32)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        return bool(int(tt.item()))
 
     def max_over_ranks(seconds):
         if use_dist:
@@ -383,20 +452,32 @@ def main():
             return float(tt.item())
         return seconds
 
-    def timed_region(fn, steps, warmup):
-        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
-        for _ in range(warmup):
-            fn()
-        torch.cuda.synchronize()
-        barrier()
+    def timed_region(fn, steps, warmup, leg="leg"):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.  The two
+        barriers are all_ok(): a failure on one rank ends the leg on all of them."""
+        err = None
+        try:
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+        except Exception as exc:      # noqa: BLE001 -- reported, and every rank must still reach the collective below
+            err = exc
+        if not all_ok(err is None):
+            raise LegFailed("%s: %s" % (leg, repr(err) if err is not None else "another rank failed during warm-up"))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
+        try:
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+        except Exception as exc:      # noqa: BLE001
+            err = exc
+        ok = all_ok(err is None)
         torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        return max_over_ranks(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
+        if not ok:
+            raise LegFailed("%s: %s" % (leg, repr(err) if err is not None else "another rank failed in the timed region"))
+        return max_over_ranks(dt)
 
     # -- the headline step ------------------------------------------------------------------------
     ktimes = {"stft_fwd": [], "mel": [], "istft": []}
@@ -410,6 +491,7 @@ def main():
         # allocations are the faster ones, tools/placement_probe2.py: 0.677 / 0.685 / 0.685 / 0.703 ms for four buffers
         # in allocation order) -- the timed steps then alternated 1.49 / 1.60 ms.
         last.clear()
+        maybe_fail("step")
         e = None
         if record:
             e = [ev() for _ in range(4)]
@@ -437,6 +519,7 @@ def main():
         """log-mel (B, T, 128) from the fused kernel (the spectrum never goes to HBM) and its DCT-II, 40
         coefficients, channel-major (B, 40, T) like the reference's MFCC layout."""
         from acids_transforms_amd import ops as _ops
+        maybe_fail("config4")
         _, _, logmel = _ops.stft_mel_forward(x, mfcc.window, mfcc._band, "log", None, None, eps=1e-10, power=2,
                                              want_spectrum=False)
         coef = _ops.mel_forward_real(logmel, mfcc.dct, None, None, channel_major_T=logmel.shape[-2])
@@ -445,7 +528,7 @@ def main():
     def config4_figures(steps, warmup):
         from acids_transforms_amd.dist import all_gather_features
         res = {}
-        t_compute = timed_region(config4_compute, steps, warmup)
+        t_compute = timed_region(config4_compute, steps, warmup, "config4 compute")
         res["compute_only"] = {"frames_per_s": world * frames_per_step * steps / t_compute,
                                "ms_per_step": t_compute / steps * 1e3}
         if use_dist and not rehearsal:
@@ -470,9 +553,12 @@ def main():
                             if h is not None:
                                 pending.append(h)
 
-                t = timed_region(fn, steps, warmup)
-                for h in pending:
-                    h.wait()
+                try:
+                    t = timed_region(fn, steps, warmup, "config4 " + what)
+                finally:
+                    for h in pending:
+                        h.wait()
+                    pending.clear()
                 torch.cuda.synchronize()
                 return {"frames_per_s": world * frames_per_step * steps / t, "ms_per_step": t / steps * 1e3}
 
@@ -485,8 +571,21 @@ def main():
                        "(barrier + synchronize on both sides)" % B)
         return res
 
+    def fail_all_ranks(exc):
+        """A collective leg of the headline failed somewhere: every rank is here (LegFailed is raised on all of them),
+        rank 0 says so on stdout, everybody exits non-zero."""
+        if rank == 0:
+            print(json.dumps({"error": "rank failure inside a timed region: %s" % exc, "n_gpus": world}))
+            sys.stdout.flush()
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(6)
+
     if config4:
-        c4 = config4_figures(args.steps, args.warmup)
+        try:
+            c4 = config4_figures(args.steps, args.warmup)
+        except LegFailed as exc:
+            fail_all_ranks(exc)
         key = "with_allgather_fp32" if "with_allgather_fp32" in c4 else "compute_only"
         value = c4[key]["frames_per_s"]
         ms_per_step = c4[key]["ms_per_step"]
@@ -509,42 +608,67 @@ def main():
         return
 
     # settle: the power controller's transient of a fresh process is over before the W warm-up steps start
-    # (reported as `settle_steps`; the W warm-up steps and the K timed steps follow as the contract says)
+    # (reported as `settle_steps`; the W warm-up steps and the K timed steps follow as the contract says).  The first
+    # W + K steps of the process are what `--settle-steps 0` would have timed: they are clocked on the way
+    # (`fresh_process_ms_per_step`, HIP events, no host synchronisation) so that both figures come from one run.
     settled = 0
-    if args.settle_steps >= 0:
-        for _ in range(args.settle_steps):
-            step()
-        settled = args.settle_steps
-    else:
-        # adaptive: 10-step chunks timed with events; the host waits for chunk k while chunk k + 1 is already queued,
-        # so the GPU never idles (an idle gap is itself a transient: the first step after one runs ~12 % slow)
-        marks = [ev()]
-        marks[0].record()
-        means = []
-        while settled < 600:
-            for _ in range(10):
+    fresh_ms = None
+    err = None
+    try:
+        if args.settle_steps != 0:
+            fa, fb = ev(), ev()
+            for _ in range(args.warmup):
                 step()
-            settled += 10
-            marks.append(ev())
-            marks[-1].record()
-            if len(marks) >= 3:
-                marks[-2].synchronize()
-                means.append(marks[-3].elapsed_time(marks[-2]) / 10.0)
-            if settled >= 40 and len(means) >= 3 and max(means[-3:]) <= 1.015 * min(means[-3:]):
-                break
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
+            fa.record()
+            for _ in range(args.steps):
+                step()
+            fb.record()
+            settled = args.warmup + args.steps
+        if args.settle_steps > 0:
+            for _ in range(max(0, args.settle_steps - settled)):
+                step()
+            settled = max(settled, args.settle_steps)
+        elif args.settle_steps < 0:
+            # adaptive: 10-step chunks timed with events; the host waits for chunk k while chunk k + 1 is already queued,
+            # so the GPU never idles (an idle gap is itself a transient: the first step after one runs ~12 % slow)
+            marks = [ev()]
+            marks[0].record()
+            means = []
+            while settled < 600:
+                for _ in range(10):
+                    step()
+                settled += 10
+                marks.append(ev())
+                marks[-1].record()
+                if len(marks) >= 3:
+                    marks[-2].synchronize()
+                    means.append(marks[-3].elapsed_time(marks[-2]) / 10.0)
+                if settled >= 40 and len(means) >= 3 and max(means[-3:]) <= 1.015 * min(means[-3:]):
+                    break
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if args.settle_steps != 0:
+            fresh_ms = fa.elapsed_time(fb) / max(1, args.steps)
+    except Exception as exc:          # noqa: BLE001 -- every rank must reach the collective below
+        err = exc
+    if not all_ok(err is None):
+        fail_all_ranks("settle / warm-up: %s" % (repr(err) if err is not None else "another rank failed"))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs = []
-    for _ in range(args.steps):
-        evs.append(step(record=True))
+    try:
+        for _ in range(args.steps):
+            evs.append(step(record=True))
+        torch.cuda.synchronize()
+    except Exception as exc:          # noqa: BLE001
+        err = exc
+    ok = all_ok(err is None)
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed = time.perf_counter() - t0
+    if not ok:
+        fail_all_ranks("timed region: %s" % (repr(err) if err is not None else "another rank failed"))
+    elapsed = max_over_ranks(elapsed)
     for e in evs:
         ktimes["stft_fwd"].append(e[0].elapsed_time(e[1]))
         ktimes["mel"].append(e[1].elapsed_time(e[2]))
@@ -571,6 +695,9 @@ def main():
         from oracle import oracle as O
         ids = sorted({0, B // 2 - 1 if B > 1 else 0, B - 1})
         xs = x[ids].cpu()
+        corrupt = os.environ.get("ACIDS_BENCH_CORRUPT")       # dev only ("X" | "feat" | "y"): the test of the exit status
+        if corrupt in last:
+            last[corrupt].view(-1)[: last[corrupt].numel() // 2].zero_()
         Xg, fg, yg = (last[k][ids].cpu() for k in ("X", "feat", "y"))
         w = O.hann_window(N_FFT)
         Xr = O.stft_forward(xs, w, N_FFT, HOP)
@@ -586,9 +713,6 @@ def main():
         return {"clips": ids, "max_rel": max(r.values()), "per_output": r, "tolerance": 1e-5,
                 "ok": bool(max(r.values()) < 1e-5),
                 "note": "outputs of the last timed step (rank 0) vs the oracle on CPU, max|d|/max|ref|"}
-
-    if rank == 0:
-        guarded("parity_spot_check", parity_spot_check)
 
     def hbm_entry(name, bytes_per_frame, ms=None):
         ms = avg[name] if ms is None else ms
@@ -612,7 +736,7 @@ def main():
         # one kernel reads the audio and writes spectrum + features: 1024 + 4104 + 512 bytes per frame
         kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD + 4 * N_MELS), hbm_entry("istft", BYTES_ISTFT)]
         kernels[0]["kernel"] = "stft_fwd+mel (fused)"
-        if rank == 0:                                            # cheap (~40 launches): kept under --no-extras too
+        if rank == 0 and world == 1:                             # cheap (~300 launches): kept under --no-extras too
             # 25 launches before the 30 timed ones: a change of kernel is a change of power draw, and the chip's
             # power controller takes ~25 launches to settle on the new sustained clock (tools/ramp_probe.py)
             Xs = stft(x)
@@ -629,6 +753,23 @@ def main():
             kernels[-1]["kernel"] = "stft_fwd+mel, features only (spectrum not stored; outside the step)"
             kernels[-1]["note"] = ("literal configs[1] 'fwd': 1536 algorithmic B/frame; VALU/LDS-bound (FFT + band walk per "
                                    "frame), not HBM-bound -- reported against its own HBM roofline for honesty")
+            # the reference's DEFAULT bank: Magnitude() builds 513 mel filters (spectral_repr.py:170-189); SURVEY 8d C2
+            # asks for both.  Fused spectrum + features: 1024 + 4104 + 2052 B/frame; features only (the README chain's
+            # forward, README.md:48-50): 1024 + 2052.
+            mag513 = A.Magnitude(sr=SR, n_fft=N_FFT, mode="unipolar", contrast="log1p").to(dev)
+            Xs = stft(x[:8])
+            mag513.scale_data(Xs)
+            del Xs
+            if mag513.can_fuse_with(stft, x):
+                avg["fused_mel513"] = timed_ms(lambda: mag513.forward_fused(stft, x, return_spectrum=True), 30, 25)
+                kernels.append(hbm_entry("fused_mel513", BYTES_STFT_FWD + 4 * F_BINS))
+                kernels[-1]["kernel"] = "stft_fwd+mel513 (fused, reference-default 513-filter bank; outside the step)"
+                off5, sc5 = mag513._affine()
+                avg["fwd_features_only_mel513"] = timed_ms(lambda: _ops.stft_mel_forward(
+                    x, stft.window[:N_FFT], mag513._banded(), "log1p", off5, sc5, mag513._eps, want_spectrum=False), 30, 25)
+                kernels.append(hbm_entry("fwd_features_only_mel513", HOP * 4 + 4 * F_BINS))
+                kernels[-1]["kernel"] = "stft_fwd+mel513, features only (README chain forward; outside the step)"
+            del mag513
     else:
         kernels = [hbm_entry("stft_fwd", BYTES_STFT_FWD), hbm_entry("istft", BYTES_ISTFT)]
     if "mel" in avg and avg["mel"] > 0:
@@ -640,6 +781,16 @@ def main():
     roof["traffic"], roof["traffic_source"] = pmc_traffic(dominant if (fused or dominant != "stft_fwd") else "stft_fwd_unfused")
     roof["kernel"] = {"stft_fwd": "stft1024_h256_fwd_kernel (fused mel epilogue)" if fused else "stft1024_h256_fwd_kernel",
                       "istft": "istft1024_ola_kernel"}[dominant]
+    # everything else the step and its neighbours run, where the driver's record can see it (it keeps `roofline` whole
+    # and only the NAMES of extra keys): the step's other kernel, the whole step, and the forms outside the step
+    step_bytes = (BYTES_STFT_FWD + (4 * N_MELS if fused else 0) + BYTES_ISTFT) if fused else (BYTES_STFT_FWD + BYTES_MEL + BYTES_ISTFT)
+    step_gbs = frames_per_step * step_bytes / (ms_per_step * 1e-3) / 1e9 if world == 1 else None
+    roof["others"] = [{k: v for k, v in kk.items() if k in ("kernel", "achieved", "frac", "ms", "algorithmic_bytes_per_frame")}
+                      for kk in kernels if kk["kernel"] != (kernels[0] if dominant == "stft_fwd" else kernels[1])["kernel"]]
+    roof["whole_step"] = {"algorithmic_bytes_per_frame": step_bytes, "ms": round(ms_per_step, 4),
+                          "achieved": None if step_gbs is None else round(step_gbs, 1),
+                          "frac": None if step_gbs is None else round(step_gbs / HBM_PEAK_GBS, 4),
+                          "note": "both kernels of the step over the step's wall time (launch gaps included), per GPU"}
 
     # -- side measurements -----------------------------------------------------------------------------------
     def extra_h2d_inclusive():
@@ -885,23 +1036,29 @@ def main():
         dt = time.perf_counter() - t1
         return {"seconds": dt, "frames_per_s": frames_per_step / dt, "iterations": 30}
 
+    # Order: every leg that holds collectives runs on ALL ranks first (config4 is the only one;
+    # `guarded` records its LegFailed identically on every rank); the rank-0-only legs follow and hold none, so no rank
+    # ever waits in a collective for one that is busy elsewhere.  They are single-GPU figures and run at N = 1 only:
+    # at N > 1 the other ranks would sit idle for a minute, and the N = 1 line of the same sweep carries them.
     pghi_inputs = {}
     northstar_inputs = {}
     if not args.no_extras:
-        if rank == 0:
+        guarded("config4", lambda: config4_figures(max(10, args.steps // 5), 3))
+    if rank == 0:
+        guarded("parity_spot_check", parity_spot_check)          # CPU oracle on three clips of the last timed step
+    if not args.no_extras:
+        if rank == 0 and world == 1:
             guarded("hbm_probe", extra_hbm_probe)
             guarded("h2d_inclusive", extra_h2d_inclusive)
             guarded("other_hops", extra_other_hops)
             guarded("other_sizes", extra_other_sizes)
             guarded("griffin_lim_invert", extra_griffin_lim)
             guarded("phase_representations", extra_phase_repr)
-        guarded("config4", lambda: config4_figures(max(10, args.steps // 5), 3))     # all ranks: it holds collectives
-        if rank == 0 and args.pghi_clips > 0:
-            guarded("pghi_invert", lambda: extra_pghi(pghi_inputs))
-            guarded("northstar_pipeline", lambda: extra_northstar(northstar_inputs))
-        if rank == 0 and args.streams > 0:
-            guarded("realtime_dgt_stream", extra_stream)
-        barrier()
+            if args.pghi_clips > 0:
+                guarded("pghi_invert", lambda: extra_pghi(pghi_inputs))
+                guarded("northstar_pipeline", lambda: extra_northstar(northstar_inputs))
+            if args.streams > 0:
+                guarded("realtime_dgt_stream", extra_stream)
 
     result = {
         "metric": "spectrogram frames/sec (fwd+invert), n_fft=1024 hop=256",
@@ -916,6 +1073,9 @@ def main():
         "roofline": roof,
         "kernels": kernels,
         "settle_steps": settled,
+        "fresh_process_ms_per_step": round(fresh_ms if fresh_ms is not None else ms_per_step, 4),
+        "fresh_process_note": ("steps W+1 .. W+K of this process's life, before any settling: what `--settle-steps 0` "
+                               "times (HIP events around the K steps); `ms_per_step` is the settled figure"),
         "timed_step_ms": {"first": step_ms_events[0], "last": step_ms_events[-1], "min": min(step_ms_events),
                           "max": max(step_ms_events), "all": step_ms_events,
                           "note": "per-step kernel time (HIP events) inside the timed region: flat = steady state"},
@@ -931,6 +1091,10 @@ def main():
             if th <= hc["affinity"]:
                 sweep[th] = cpu_baseline(th, 8 if th == 1 else 96, budget_s=3.0)
         best = max(sweep, key=lambda t: sweep[t]["value"])
+        for v in sweep.values():
+            # `cores` (the contract's field) = threads used; next to it what those threads ran on
+            v.update({"threads": v["cores"], "cpu_share": hc["cgroup_quota"] if hc["cgroup_quota"] is not None else hc["affinity"],
+                      "host_threads": hc["os_cpu_count"]})
         result["cpu_baseline"] = sweep[best]
         result["cpu_baseline_1thread"] = sweep[1]
         result["cpu_baseline_sweep"] = {str(t): round(v["value"], 1) for t, v in sweep.items()}
@@ -952,16 +1116,23 @@ def main():
             except Exception:
                 pass
     failed = sorted(k for k in result if k.endswith("_error"))
+    unverified = verification_failures(result)
+    result["verification"] = {"spot_checks_failed": unverified, "ok": not unverified}
+    status = exit_status(result)
     if rank == 0:
         print(json.dumps(result))
         sys.stdout.flush()
     if use_dist:
+        # every rank arrives with the same keys (collective legs fail on all ranks together), hence the same status
         dist.destroy_process_group()
+    if unverified:
+        sys.stderr.write("bench.py: spot check(s) of timed results FAILED: %s\n" % ", ".join(unverified))
     if failed:
         # the line above is complete and valid, but a side measurement raised: say so with the exit status
         # (the driver's record lists key names only; a silent `*_error` string would pass unnoticed)
         sys.stderr.write("bench.py: side measurement(s) failed: %s\n" % ", ".join(failed))
-        sys.exit(4)
+    if status:
+        sys.exit(status)
 
 
 def pmc_traffic(key):

@@ -35,11 +35,24 @@ extern "C" {
 #define AT_EWORKSPACE (-4) /* workspace too small */
 #define AT_ELAUNCH (-5)    /* HIP launch / runtime error */
 
-/* Returns 3.  History: 2 early in round 2 (at_sinebank_realtime gained the window argument; at_mel_*bf16*, at_oadd_push
+/* Returns 4.  History: 4 in round 4 (at_set_variant / at_get_variant).  Earlier history: 2 early in round 2 (at_sinebank_realtime gained the window argument; at_mel_*bf16*, at_oadd_push
  * added); 3 later in round 2 (at_pghi_realtime_seeded, at_phase_*_strided / _polar, at_cartesian_*).  Round 3 changed
  * kernels only: no signature moved. */
 int at_abi_version(void);
 const char *at_error_string(int code);
+
+/* Kernel variants.  The library decides from a call's arguments which kernel runs; it reads NO environment variables
+ * (the A/B switches of tools/ab*.sh exist only in -DAT_DEV_SWITCHES builds).  Where two kernels compute the same
+ * result -- a form specialised for the headline shapes and the generic one -- this process-wide table lets a caller force
+ * the generic one; the parity tests use it to compare the two.  No reference counterpart (the reference has one
+ * implementation of everything).  value: 0 = default; returns AT_EINVAL for an unknown variant or value. */
+#define AT_VARIANT_EPILOGUE 0          /* 1: generic mel epilogue / projection even for the 128-mel headline bank */
+#define AT_VARIANT_FRAME_KERNELS 1     /* 1: frame-at-a-time forward at n_fft 512 / 2048 / 4096 (no sliding window) */
+#define AT_VARIANT_SMALL_PROJECTION 2  /* 1: row kernel instead of the matrix-core form of the K <= 128 projection */
+#define AT_VARIANT_SCAN_LAYOUT 3       /* 1: flattened columns instead of one block per clip in the phase scans */
+#define AT_VARIANT_PGHI_KERNEL 4       /* 1: winner-bit offline heap kernel; 2: single-lane heap kernels */
+int at_set_variant(int which, int value);
+int at_get_variant(int which);
 
 /* One-time per-device setup (twiddle tables).  Synchronous; call before capture. */
 int at_init(int device);

@@ -118,7 +118,7 @@ def test_bench_launcher_never_reports_a_smaller_job():
     # rehearsal mode skips the device-count check, so both ranks really start (and fail: no device here);
     # the parent must relay that failure
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"ACIDS_BENCH_REHEARSAL": "1"})
-    assert r.returncode != 0 and r.stdout.count("no ROCm device") == 2
+    assert r.returncode != 0 and r.stdout.count("no ROCm device") >= 1      # (the parent stops the other rank at the first failure)
 
 
 def test_bench_launcher_parent_never_imports_torch(tmp_path):
@@ -147,14 +147,18 @@ def test_visible_gpu_count_follows_the_runtime_masks(monkeypatch):
     import bench
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         monkeypatch.delenv(var, raising=False)
-    total = bench.visible_gpu_count()
+    total, known = bench.visible_gpu_census()
     assert total >= 0
+
+    def cap(k):            # a mask is an upper bound; the topology, where readable, lowers it
+        return min(total, k) if known else k
+
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
-    assert bench.visible_gpu_count() == 0
+    assert bench.visible_gpu_census() == (0, True)
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,-1,2")
-    assert bench.visible_gpu_count() == min(total, 2)          # the list ends at the first negative entry
+    assert bench.visible_gpu_census() == (cap(2), True)          # the list ends at the first negative entry
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
-    assert bench.visible_gpu_count() == min(total, 1)
+    assert bench.visible_gpu_count() == cap(1)
 
 
 def test_shard_bounds_cover_everything():

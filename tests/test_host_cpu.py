@@ -108,12 +108,37 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(L, name), "missing export: " + name
     assert sorted(_lib.exported_symbols()) == declared            # the Python binding covers the whole ABI
     lib = _lib.lib()
-    assert lib.at_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.at_abi_version() == _lib.ABI_VERSION == 4
     assert lib.at_error_string(-2).decode() == "unsupported configuration"
     assert lib.at_istft_workspace_bytes(4, 10, 1024, 256) == 0
     assert lib.at_istft_workspace_bytes(4, 10, 512, 128) == 0 and lib.at_istft_workspace_bytes(4, 10, 2048, 512) == 0
     assert lib.at_istft_workspace_bytes(4, 10, 256, 64) == 4 * 10 * 256 * 4
     assert lib.at_pghi_offline_workspace_bytes(2, 10, 513) >= 2 * (3 * 5130 * 4 + 5132 * 8)
+
+
+def test_library_reads_no_environment_and_variants_are_explicit():
+    """the shipped library takes no decisions from environment variables -- no getenv in its sources
+    outside the -DAT_DEV_SWITCHES accessor, none among its dynamic imports -- and the kernel variants the parity tests
+    need are an explicit, validated C-ABI table."""
+    import subprocess
+    csrc = os.path.join(ROOT, "acids_transforms_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")) and f != "variants.h":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    v = open(os.path.join(csrc, "variants.h")).read()
+    assert v.count("getenv(") == 2 and "#ifdef AT_DEV_SWITCHES" in v      # one use, one mention, both in the dev branch
+    so = os.path.join(ROOT, "acids_transforms_amd", "libacids_hip.so")
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+    assert "getenv" not in undefined
+    lib = _lib.lib()
+    for which in _lib.VARIANTS.values():
+        assert lib.at_get_variant(which) == 0
+    assert lib.at_set_variant(99, 1) == -1 and lib.at_set_variant(0, 7) == -1 and lib.at_get_variant(-1) == -1
+    with _lib.variant("pghi_kernel", 2):
+        assert lib.at_get_variant(_lib.VARIANTS["pghi_kernel"]) == 2
+        with _lib.variant("epilogue", 1):
+            assert lib.at_get_variant(_lib.VARIANTS["epilogue"]) == 1
+    assert all(lib.at_get_variant(w) == 0 for w in _lib.VARIANTS.values())
 
 
 def test_product_never_touches_the_oracle():

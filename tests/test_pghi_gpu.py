@@ -275,13 +275,13 @@ def test_realtime_seeded_draws_are_standard_normal(dev):
 
 
 def test_winner_bit_kernel_stays_exact(dev):
-    """The opt-in winner-bit heap kernel (ACIDS_PGHI_KERNEL=wbit; the variable is read once per process, hence the child
-    process) must keep producing the C oracle's pop order: ties, sparse spectra, batches of unequal clips."""
+    """The opt-in winner-bit heap kernel (at_set_variant(AT_VARIANT_PGHI_KERNEL, 1); the fuzz tool sets it from
+    FUZZ_PGHI_KERNEL) must keep producing the C oracle's pop order: ties, sparse spectra, batches of unequal clips."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ACIDS_PGHI_KERNEL="wbit", FUZZ_CASES="24", FUZZ_SEED="3")
+    env = dict(os.environ, FUZZ_PGHI_KERNEL="1", FUZZ_CASES="24", FUZZ_SEED="3")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pghi.py")], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -14,6 +14,7 @@ import acids_transforms_amd as A
 from acids_transforms_amd import ops
 from acids_transforms_amd.utils import misc as M
 from conftest import rel_max
+from acids_transforms_amd._lib import variant
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -164,7 +165,7 @@ def test_against_oracle_random_shapes(dev):
 def test_clip_per_block_scans_equal_flat_layout_and_oracle(dev, shape):
     """>= 64 clips with rows of >= 256 bins that are not whole 64-byte segments take the one-block-per-clip layout
     (2 or 4 columns per thread, wavefronts in lockstep): bit-identical to the flattened-column layout
-    (ACIDS_SCAN_FLAT=1) for every mode, bit-identical to the oracle on real input, 1e-5 from it through atan2."""
+    (`variant("scan_layout", 1)`) for every mode, bit-identical to the oracle on real input, 1e-5 from it through atan2."""
     import os
     gen = torch.Generator().manual_seed(sum(shape))
     X = (torch.randn(*shape, generator=gen) * torch.exp(2j * np.pi * torch.rand(*shape, generator=gen))).to(torch.complex64)
@@ -183,11 +184,8 @@ def test_clip_per_block_scans_equal_flat_layout_and_oracle(dev, shape):
         return {k: cpu(v) for k, v in out.items()}
 
     got = run()
-    os.environ["ACIDS_SCAN_FLAT"] = "1"
-    try:
+    with variant("scan_layout", 1):
         flat = run()
-    finally:
-        del os.environ["ACIDS_SCAN_FLAT"]
     for k in got:
         assert torch.equal(got[k], flat[k]), (k, shape)
     assert torch.equal(got["unwrap_r"], O.unwrap(y))

@@ -10,6 +10,7 @@ import torch
 
 import acids_transforms_amd as A
 from conftest import rel_max
+from acids_transforms_amd._lib import variant
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -460,9 +461,8 @@ def test_sliding_aligned_forward_2048_4096_full_batch(dev, n, monkeypatch):
     Xr = O.stft_forward(x[ids], O.hann_window(n), n, h)
     assert X.shape[1:] == Xr.shape[1:]
     assert rel_max(cpu(X[ids]), Xr.numpy()) < TOL
-    monkeypatch.setenv("ACIDS_STFT%d_FRAMES" % n, "1")
-    Xf = st(xd)
-    monkeypatch.delenv("ACIDS_STFT%d_FRAMES" % n)
+    with variant("frame_kernels", 1):
+        Xf = st(xd)
     scale = float(torch.view_as_real(Xf).abs().max())
     assert float((torch.view_as_real(X) - torch.view_as_real(Xf)).abs().max()) < 3e-6 * scale
     del X, Xf
@@ -488,9 +488,8 @@ def test_sliding_aligned_forward_512_full_batch(dev, monkeypatch):
     Xr = O.stft_forward(x[ids], O.hann_window(n), n, h)
     assert X.shape[1:] == Xr.shape[1:]
     assert rel_max(cpu(X[ids]), Xr.numpy()) < TOL
-    monkeypatch.setenv("ACIDS_STFT512_FRAMES", "1")
-    Xf = st(xd)
-    monkeypatch.delenv("ACIDS_STFT512_FRAMES")
+    with variant("frame_kernels", 1):
+        Xf = st(xd)
     scale = float(torch.view_as_real(Xf).abs().max())
     assert float((torch.view_as_real(X) - torch.view_as_real(Xf)).abs().max()) < 3e-6 * scale
     del X, Xf

@@ -13,6 +13,9 @@ from oracle import oracle as O  # noqa: E402
 dev = torch.device("cuda")
 rng = np.random.RandomState(int(os.environ.get("FUZZ_SEED", "0")))
 n_cases = int(os.environ.get("FUZZ_CASES", "60"))
+if os.environ.get("FUZZ_PGHI_KERNEL"):      # 1: winner-bit kernel, 2: single-lane kernel (C ABI at_set_variant)
+    from acids_transforms_amd._lib import lib, check, VARIANTS  # noqa: E402
+    check(lib().at_set_variant(VARIANTS["pghi_kernel"], int(os.environ["FUZZ_PGHI_KERNEL"])), "at_set_variant")
 pops = 0
 for i in range(n_cases):
     n_fft = int(rng.choice([32, 128, 512, 1024]))

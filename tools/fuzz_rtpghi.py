@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Realtime PGHI against the C oracle on random sizes (streams, frames per chunk, n_fft), with tied and sparse
-magnitudes.  The serial single-lane kernel (ACIDS_PGHI_SERIAL=1 in a second process) must agree bit for bit, the
+magnitudes.  The serial single-lane kernel (FUZZ_PGHI_KERNEL=2 in a second process: at_set_variant) must agree bit for bit, the
 oracle within the tests' phase tolerance."""
 import os
 import sys
@@ -14,6 +14,9 @@ from oracle import oracle as O  # noqa: E402
 dev = torch.device("cuda")
 rng = np.random.RandomState(int(os.environ.get("FUZZ_SEED", "0")))
 n_cases = int(os.environ.get("FUZZ_CASES", "60"))
+if os.environ.get("FUZZ_PGHI_KERNEL"):      # 2: single-lane kernels (C ABI at_set_variant)
+    from acids_transforms_amd._lib import lib, check, VARIANTS  # noqa: E402
+    check(lib().at_set_variant(VARIANTS["pghi_kernel"], int(os.environ["FUZZ_PGHI_KERNEL"])), "at_set_variant")
 out = []
 for i in range(n_cases):
     n_fft = int(rng.choice([32, 128, 1024]))
