@@ -3,6 +3,7 @@
 Same class names and nn.Module API as the reference package; the arithmetic
 is hand-written HIP for gfx950 behind a C ABI (include/acids_hip.h).
 """
+from .utils import *  # noqa: F401,F403  (the reference re-exports its utils at package level: __init__.py:1)
 from .transforms import *  # noqa: F401,F403
 from ._lib import AcidsHipError, build  # noqa: F401
 

@@ -63,6 +63,39 @@ __device__ __forceinline__ void band_walk_fixed(const float* absrow, int start0,
   sum1 = s1.x + s1.y;
 }
 
+// The fixed-length walk of a bank with up to eight passes, their lengths in quads packed one per nibble of FQP (pass 0 in
+// the low nibble) -- the reference's default bank, Magnitude() at sr 44100 / n_fft 1024: 404 non-empty filters of 513 in
+// seven passes of 3, 2, 2, 1, 1, 1, 1 quads and two passes of empty filters (NP = 9, FQP = 0x001111223: a pass of zero quads
+// sums nothing and its lanes emit contrast(0)).  a_off[q]: byte offset of this lane's walk of pass q inside the LDS row of
+// magnitudes.  Every pass is straight-line code on its own packed sum.
+typedef unsigned long long fqp_t;
+constexpr int fqp_quads(fqp_t fqp, int q) { return (int)((fqp >> (4 * q)) & 15u); }
+constexpr int fqp_base(fqp_t fqp, int q) {
+  int b = 0;
+  for (int i = 0; i < q; ++i) b += fqp_quads(fqp, i);
+  return b;
+}
+template <fqp_t FQP, int NP>
+__device__ __forceinline__ void band_walk_packed(const float* absrow, const int (&a_off)[NP], const float* wlds, int lane,
+                                                 float (&sum)[NP]) {
+  const float4* w = reinterpret_cast<const float4*>(wlds) + lane;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const float4* a = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(absrow) + a_off[q]);
+    bb_v2f s = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < fqp_quads(FQP, q); ++j) {
+      const float4 av = a[j], wv = w[(fqp_base(FQP, q) + j) * 64];
+      s = __builtin_elementwise_fma((bb_v2f){av.x, av.y}, (bb_v2f){wv.x, wv.y}, s);
+      s = __builtin_elementwise_fma((bb_v2f){av.z, av.w}, (bb_v2f){wv.z, wv.w}, s);
+    }
+    sum[q] = s.x + s.y;
+    // Keep the scheduler from hoisting every pass's reads to the top (22 ds_read_b128 = 88 registers for the default
+    // bank: 200 bytes of scratch per lane and 1.86 ms instead of 1.30): a fence whenever another three quads are done.
+    if (fqp_base(FQP, q + 1) / 3 != fqp_base(FQP, q) / 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Contrast of the fused / fixed-form epilogues.  The arguments are >= eps = 1.19e-7 (never denormal), so the hardware
 // log2 (1 ulp) times ln 2 / log10 2 is within ~2 ulp of logf / log10f at a sixth of the instructions.
 __device__ __forceinline__ float band_contrast_fast(float v, int mode, float eps) {

@@ -218,12 +218,15 @@ __device__ __forceinline__ float fwd_contrast(float v, int mode, float eps) { re
 // NT: those stores non-temporal.  tools/ubench/stream_pattern2.hip prices the pattern: rows 4.7 TB/s, aligned blocks
 // 4.95, aligned + nt 5.0-5.3 (profiles/r03a_*).
 template <bool WRITE_PHASE, int MEL, int FWD_WAVES, bool TWLDS, int CMBUF = 0, bool POLAR = false, int HS = 2, int SP = 0,
-          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false, int HYB = 0, int FC = 1, bool FP2 = false, bool PW = false>
+          int FQ0 = 0, int FQ1 = 0, bool AL = false, bool NT = false, int HYB = 0, int FC = 1, bool FP2 = false, bool PW = false,
+          fqp_t FQP = 0, int FNP = 0>
 __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) void stft1024_h256_fwd_kernel(FwdRunParams p) {
   // HYB (with TWLDS): bit 0 -- the two pass twiddle tables in registers, only the merge's W1024 rows from LDS
   // (HybridTwiddles); bit 1 -- the analysis window in registers.  Both trade LDS reads (the busiest unit of these
   // kernels) for VGPRs, i.e. for the fourth wave per SIMD.
   constexpr int H = 128 * HS;
+  constexpr int kNP = FQP ? FNP : 1;
+  constexpr int kPkStride = (kNP + 3) / 4 * 4;       // dwords per lane in the packed descriptor table (16-byte rows)
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
   __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
   extern __shared__ float4 band_lds[];   // MEL != 0: the bank's weight table, sized by the launcher
@@ -250,6 +253,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
     for (int i = threadIdx.x; i < 64 * p.bank.n_passes; i += 64 * FWD_WAVES) {
       lane_tab[i] = p.bank.lane_start[i];
       lane_tab[64 * p.bank.n_passes + i] = p.bank.lane_filter[i];
+    }
+    // FQP (fixed-length epilogue of a bank with many passes, band_bank.h): ONE word per lane and pass -- the byte offset
+    // of the lane's walk in the LDS row (low 12 bits) and the byte offset of its filter in the feature row (next 12;
+    // 0xfff: no filter) -- lane-major behind the lane tables, read back 16 bytes at a time (rows of kPkStride words: 12
+    // for nine passes, which keeps the 16 lanes of a ds_read_b128 group on distinct banks).  In registers the nine words
+    // (and what the optimiser hoists out of the frame loop from them) spilled.
+    if constexpr (FQP != 0) {
+      int* pk_tab = lane_tab + 2 * 64 * p.bank.n_passes;
+      for (int i = threadIdx.x; i < 64 * kNP; i += 64 * FWD_WAVES) {
+        const int q = i >> 6, l = i & 63;
+        const int f = p.bank.lane_filter[i];
+        pk_tab[l * kPkStride + q] = (p.bank.lane_start[i] * 4) | ((f >= 0 ? f * 4 : 0xfff) << 12);
+      }
     }
   }
   // PW: the workgroup stays resident and takes TILES -- FWD_WAVES consecutive runs, one per wave -- in address order from
@@ -517,6 +533,59 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
       } else {
         if (sp_f[0] >= 0) frow[sp_f[0]] = f0v;
         if (sp_f[1] >= 0) frow[sp_f[1]] = f1v;
+      }
+      wave_lds_sync();
+      frow += feat_ld;
+      ++t_cur;
+    } else if constexpr (MEL != 0 && FQP != 0) {
+      static_assert(SP == 0 && CMBUF == 0 && !POLAR && !FP2 && FC == 1, "packed fixed-length epilogue: row-major log1p(|X| bank) features");
+      float* absrow = reinterpret_cast<float*>(lds);
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) absrow[col + 64 * m] = __builtin_amdgcn_sqrtf(fmaf(v[m].x, v[m].x, v[m].y * v[m].y));
+      // bin 512; entries 513 .. 639 are finite leftovers of this frame's exchanges under zero weights (fft512.h pins that)
+      if (col == 0) absrow[512] = fabsf(nyq.x);
+      wave_lds_sync();
+      const int4* pk4 = reinterpret_cast<const int4*>(lane_tab + 2 * 64 * kNP + lane * kPkStride);
+      int a_off[kNP];
+#pragma unroll
+      for (int g = 0; g < kPkStride / 4; ++g) {
+        const int4 d = pk4[g];
+        if (4 * g + 0 < kNP) a_off[4 * g + 0] = d.x & 0xfff;
+        if (4 * g + 1 < kNP) a_off[4 * g + 1] = d.y & 0xfff;
+        if (4 * g + 2 < kNP) a_off[4 * g + 2] = d.z & 0xfff;
+        if (4 * g + 3 < kNP) a_off[4 * g + 3] = d.w & 0xfff;
+      }
+      float sums[kNP];
+      band_walk_packed<FQP, kNP>(absrow, a_off, wlds, lane, sums);
+      // The lanes of a pass hold filters scattered over the whole row (passes are cut by band length, lanes placed for
+      // conflict-free magnitude reads): stored straight from the lanes, each pass is a 64-lane scatter of 4-byte stores
+      // over ~30 different 64-byte segments -- ~270 write requests per frame for 2 KB of features, more than the 4 KB
+      // spectrum row costs.  The row is put in order through the LDS slab instead (the magnitudes are dead once every
+      // walk is done) and leaves as two 1-KB stores and the last bin.
+      wave_lds_sync();
+#pragma unroll
+      for (int g = 0; g < kPkStride / 4; ++g) {
+        const int4 d = pk4[g];        // read again rather than held across the walk
+        const int dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (4 * g + k < kNP) {
+            const float fv = (band_contrast_fast(sums[4 * g + k], 1, p.eps) - mel_off) * mel_inv;
+            const int f_off = (int)((unsigned)dd[k] >> 12);
+            if (f_off != 0xfff) *reinterpret_cast<float*>(reinterpret_cast<char*>(absrow) + f_off) = fv;
+          }
+        }
+      }
+      wave_lds_sync();
+      // two 1-KB stores (16 bytes per lane; rows start on 4-byte boundaries, which dwordx4 stores accept) and the last bin
+      {
+        const float4 r0 = reinterpret_cast<const float4*>(absrow)[lane];
+        const float4 r1 = reinterpret_cast<const float4*>(absrow)[64 + lane];
+        float* dst = frow + 4 * lane;
+        __builtin_memcpy(dst, &r0, 16);
+        __builtin_memcpy(dst + 256, &r1, 16);
+        if (lane == 0) frow[512] = absrow[512];
       }
       wave_lds_sync();
       frow += feat_ld;
@@ -1027,6 +1096,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void irfft1024_frames_kernel(
 // ---------------------------------------------------------------------------
 namespace at_hip {
 
+// pass lengths of the reference's default bank at sr 44100 / n_fft 1024 in quads, one per nibble (band_bank.h)
+constexpr fqp_t kDefaultBankQuads = 0x001111223ull;
+constexpr int kDefaultBankPasses = 9;      // 513 filters: seven passes of walks, two of empty filters
+static bool bank_is(const BandBank* bank, fqp_t fqp, int n_passes) {
+  if (bank->n_passes != n_passes) return false;
+  for (int q = 0; q < bank->n_passes; ++q)
+    if (bank->pass_len[q] != 4 * fqp_quads(fqp, q)) return false;
+  return true;
+}
+
 // Counter pairs of the persistent kernels live behind the device's twiddle table (capi.hip: at_init allocates
 // kTwiddleCount float2 + kTileCtrSlots pairs, zeroed).  Every launch takes the next pair of the ring; a kernel leaves
 // its pair zeroed, so a pair is only ever in doubt if kTileCtrSlots launches are issued while one is still pending on
@@ -1090,6 +1169,7 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   // table and read their twiddles from a workgroup LDS copy, which frees 44 VGPRs for a 4th wave per SIMD to
   // cover the epilogue's LDS round trips (4 % faster than the 3-wave form, A/B on one device).
   int NW = 4;
+  bool default_bank_fixed = false;
   bool fq_logpow = false;
   bool persistent = false;
   void (*kernel)(FwdRunParams) = nullptr;
@@ -1135,6 +1215,15 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
       kernel = stft1024_h256_fwd_kernel<false, 2, 4, true, 2, false, 2, 2, 8, 2, false, false, 0, 0, true>;
       fq_logpow = true;
     }
+    // The reference's default bank -- Magnitude() at sr 44100: 404 non-empty filters of 513 in seven passes of 3, 2, 2, 1,
+    // 1, 1, 1 quads -- with log1p and |X|: the packed fixed-length epilogue (the generic one spends ~125 instructions per
+    // pass on run-time switches around a walk of one to three quads)
+    if (hop == 256 && !polar && !phase && !feat_channel_major && contrast == 1 && !power2 && bank_is(bank, kDefaultBankQuads, kDefaultBankPasses) &&
+        variant(kVarEpilogue) == 0) {
+      kernel = out ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 0, 0, 0, false, false, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>
+                   : stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 0, 0, 0, false, false, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>;
+      default_bank_fixed = true;
+    }
     if (hop == 128) {
       if (!out) kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 1>;
       else kernel = phase ? stft1024_h256_fwd_kernel<true, 1, 8, true, 0, false, 1> : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 1>;
@@ -1167,6 +1256,10 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
         kernel = stft1024_h256_fwd_kernel<false, 0, 8, true, 0, false, 2, 0, 0, 0, true, true, 0, 1, false, true>;
         persistent = true;
       }
+    } else if (al_ok && default_bank_fixed && out) {
+      kernel = store_mode == 1
+                   ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 0, 0, 0, true, false, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>
+                   : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 0, 0, 0, true, true, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>;
     } else if (al_ok && kernel == (void (*)(FwdRunParams))stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>) {
       kernel = store_mode == 1 ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, false>
                                : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, true>;
@@ -1188,6 +1281,7 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     }
     if (fq_logpow) NW = 4;
   }
+  if (default_bank_fixed) dyn_lds += (size_t)64 * ((kDefaultBankPasses + 3) / 4 * 4) * sizeof(int);   // packed descriptors
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
   const long long fpr = plan_units_per_run(B, T, slots, 8, hop == 128 ? 5 : 1);
   p.frames_per_run = fpr;

@@ -6,13 +6,30 @@ current torch stream.  No arithmetic happens in Python.
 """
 import torch
 
-from ._lib import check, device_scoped, lib, ptr, require_device, stream_ptr
+from ._lib import AcidsHipError, check, device_scoped, lib, ptr, require_device, stream_ptr
+
+
+def _no_fp64(t, what="input"):
+    """The kernels compute in fp32 / complex64.  The reference run on float64 data stays in double precision
+    (torch.stft promotes: complex128 out, reference stft.py:98-104); narrowing that silently would hand back fewer
+    digits than the caller asked for, so it is an error with the way out in the message."""
+    if t.dtype in (torch.float64, torch.complex128):
+        raise AcidsHipError("%s is %s: the MI355X kernels compute in float32 / complex64 and do not narrow silently -- "
+                            "convert explicitly (x.float() / X.to(torch.complex64)) if single precision is acceptable"
+                            % (what, str(t.dtype).replace("torch.", "")))
+    return t
 
 
 def _f32c(t):
+    _no_fp64(t)
     if t.dtype != torch.float32:
-        t = t.float()
+        t = t.float()         # integer / half inputs: widening only
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _c64(X):
+    _no_fp64(X, "spectrum")
+    return X if X.dtype == torch.complex64 else X.to(torch.complex64)
 
 
 def stft_forward(x, window, n_fft, hop, center=True, want_phase=False, T=None, clip_stride=None, L=None, B=None):
@@ -51,8 +68,7 @@ def istft(X, inv_window, n_fft, hop, env16=None, mag=None, phase=None):
     require_device(src, inv_window)
     if X is not None:
         X = X if X.is_contiguous() else X.contiguous()
-        if X.dtype != torch.complex64:
-            X = X.to(torch.complex64)
+        X = _c64(X)
     else:
         mag, phase = _f32c(mag), _f32c(phase)
         if phase.shape != mag.shape:
@@ -76,8 +92,7 @@ def irfft_frames(X, inv_window, n_fft, mag=None, phase=None):
     require_device(src, inv_window)
     if X is not None:
         X = X if X.is_contiguous() else X.contiguous()
-        if X.dtype != torch.complex64:
-            X = X.to(torch.complex64)
+        X = _c64(X)
     else:
         mag, phase = _f32c(mag), _f32c(phase)
         if phase.shape != mag.shape:
@@ -118,10 +133,9 @@ def _a_kind(x, power=1):
 
 def _prep_in(x):
     if torch.is_complex(x):
-        if x.dtype != torch.complex64:
-            x = x.to(torch.complex64)
-    elif x.dtype != torch.float32:
-        x = x.float()
+        x = _c64(x)
+    else:
+        x = _f32c(x)
     return x if x.is_contiguous() else x.contiguous()
 
 
@@ -588,7 +602,7 @@ def phase_scan(x, mode, frame_window=None, offset=None, scale=None, bare=False):
         raise AttributeError("method %s not known" % mode)
     require_device(x)
     cplx = x.is_complex()
-    x = x.to(torch.complex64) if cplx else _f32c(x)
+    x = _c64(x) if cplx else _f32c(x)
     x = x if x.is_contiguous() else x.contiguous()
     B, T, F = _btf(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)

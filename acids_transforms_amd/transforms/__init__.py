@@ -3,7 +3,7 @@ from .base import (AudioTransform, ComposeAudioTransform, NotInvertibleError, In
 from .stft import STFT, RealtimeSTFT
 from .dgt import DGT, RealtimeDGT, DGT_INVERSION_MODES
 from .norm import Normalize
-from .spectral_repr import Magnitude
+from .spectral_repr import Magnitude, Dummy
 from .phase_repr import Real, Imaginary, Phase, IF, SpectralRepresentation, Cartesian, Polar, PolarIF
 from .mel import MFCC
 from .oadd import OverlapAdd

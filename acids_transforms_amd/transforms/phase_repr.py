@@ -32,7 +32,7 @@ __all__ = ["Real", "Imaginary", "Phase", "IF", "SpectralRepresentation", "Cartes
 
 def _as_complex(x: torch.Tensor) -> torch.Tensor:
     """Tensor.angle() of a real tensor is 0 / pi: give the scan kernels a complex view of real input."""
-    return x if x.is_complex() else torch.complex(x.float(), torch.zeros_like(x, dtype=torch.float32))
+    return x if x.is_complex() else torch.complex(ops._f32c(x), torch.zeros_like(x, dtype=torch.float32))
 
 
 def _pad_last_bin(x: torch.Tensor) -> torch.Tensor:

@@ -23,8 +23,13 @@ __all__ = ["Magnitude"]
 ContrastModeType = Union[None, str]
 
 
-class _Identity(AudioTransform):
+class Dummy(AudioTransform):
+    """The no-op stage the reference puts where a representation has no normalisation (spectral_repr.py:17-18,
+    25-26); `mode` is what the `__repr__`s of the representations print for it."""
     mode = None
+
+
+_Identity = Dummy
 
 
 class Magnitude(AudioTransform):
@@ -52,6 +57,9 @@ class Magnitude(AudioTransform):
         self.n_fft = n_fft
         if dtype is None:
             dtype = torch.get_default_dtype()
+        if dtype != torch.float32:
+            raise ops.AcidsHipError("dtype=%s: the MI355X kernels compute in float32 / complex64 only (construct with "
+                                    "dtype=None or torch.float32)" % str(dtype).replace("torch.", ""))
         if eps is None:
             eps = torch.finfo(dtype).eps
         self.register_buffer("eps", torch.tensor(eps))

@@ -64,6 +64,11 @@ class STFT(AudioTransform):
     # -- construction helpers shared with DGT ---------------------------------
     def _register_common_buffers(self, dtype):
         dtype = dtype or torch.get_default_dtype()
+        if dtype != torch.float32:
+            # The reference's `dtype` types its eps buffer and is meant for double-precision use (stft.py:36-47).  There
+            # is no fp64 kernel behind this class: say so at construction rather than compute in fp32 under that name.
+            raise ops.AcidsHipError("dtype=%s: the MI355X kernels compute in float32 / complex64 only (construct with "
+                                    "dtype=None or torch.float32)" % str(dtype).replace("torch.", ""))
         self.register_buffer("n_fft", torch.zeros(1).long())
         self.register_buffer("hop_length", torch.zeros(1).long())
         self.register_buffer("window", torch.zeros(MAX_NFFT))
@@ -363,8 +368,7 @@ class RealtimeSTFT(STFT):
         n = self._n_fft
         if x.shape[-1] != n:
             raise RuntimeError("RealtimeSTFT expects frames of n_fft=%d samples, got %d" % (n, x.shape[-1]))
-        if x.dtype != torch.float32:
-            x = x.float()
+        x = ops._f32c(x)          # raises on float64 (no silent narrowing); widens integer / half inputs
         out_shape = x.shape[:-1] + (n // 2 + 1,)
         xt, B, T, clip_stride, hop, L = _as_clip_layout(x, n)
         X = ops.stft_forward(xt, self.window[:n], n, hop, center=False, T=T, clip_stride=clip_stride, L=L, B=B)

@@ -1,9 +1,18 @@
 """Shape helpers shared by the transforms (reference utils/misc.py:138-178)."""
-__all__ = ["pad", "frame", "n_frames", "reshape_batches", "get_fft_idx", "deriv", "unwrap", "fdiff_forward", "fdiff_backward", "fdiff_central",
+__all__ = ["format_input_data", "pad", "frame", "n_frames", "reshape_batches", "get_fft_idx", "deriv", "unwrap", "fdiff_forward", "fdiff_backward", "fdiff_central",
            "fint_forward", "fint_backward", "fint_central"]
 from typing import Tuple
 
 import torch
+
+
+def format_input_data(x: torch.Tensor, dim=-1):
+    """Present because the reference exports it (utils/misc.py:61-63): there it splits `x.shape` at `dim` into a batch
+    part and a data part and then returns NOTHING (no return statement).  Same here, on purpose: anything else would
+    be a different function under the same name; `reshape_batches` is the one that does the job."""
+    batch_size = x.shape[:dim]          # noqa: F841 -- as in the reference: computed, not returned
+    data_size = x.shape[dim:]           # noqa: F841
+    return None
 
 
 def pad(tensor: torch.Tensor, target_size: int, dim: int):

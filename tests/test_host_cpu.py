@@ -226,3 +226,67 @@ def test_periodic_derivative_helpers():
     assert float((deriv(x, float("inf")) - want).abs().max()) < 1e-9
     assert float((deriv(x, 4) - want).abs().max()) < 2e-4 * float(want.abs().max())
     assert float((deriv(x, 2) - want).abs().max()) < 2e-3 * float(want.abs().max())
+
+
+def test_package_surface_follows_the_reference():
+    """what `from acids_transforms import *` gives a user (the reference re-exports utils and
+    transforms at package level, __init__.py:1-2, utils/__init__.py:1-2) exists here under the same names -- the
+    helpers included: `heappush` / `heappop` (utils/heapq.py), `format_input_data` (utils/misc.py:61-63, which returns
+    None there and here), and `Dummy` where the reference keeps it (spectral_repr.py:17)."""
+    names = ["unwrap", "import_data", "format_input_data", "fdiff_forward", "fdiff_backward", "fdiff_central", "fint_forward",
+             "fint_backward", "fint_central", "deriv", "get_fft_idx", "pad", "frame", "reshape_batches", "heappush",
+             "heappop", "AudioTransform", "ComposeAudioTransform", "NotInvertibleError", "Mono", "Stereo", "MidSide",
+             "Window", "MuLaw", "STFT", "RealtimeSTFT", "DGT", "RealtimeDGT", "Normalize", "Real", "Imaginary", "Magnitude",
+             "Phase", "IF", "Cartesian", "Polar", "PolarIF", "MFCC", "OneHot", "Squeeze", "Unsqueeze", "Transpose", "OverlapAdd"]
+    missing = [n for n in names if not hasattr(A, n)]
+    assert not missing, missing
+    from acids_transforms_amd.transforms import spectral_repr
+    assert issubclass(spectral_repr.Dummy, A.AudioTransform)
+    assert isinstance(A.Magnitude(mode=None).norm, spectral_repr.Dummy)
+    assert A.format_input_data(torch.zeros(2, 3, 4), dim=-1) is None
+
+
+def test_host_heap_reproduces_the_recorded_pop_order(golden):
+    """`heappush` / `heappop` with the reference's ordering rule (strict `<` on the key, right child on ties): the flood of
+    dgt.py:168-220 written out on the host with these two functions pops the bins of the golden cases -- noise, the
+    piecewise-constant TIE case, a sparse one with reseeds -- in exactly the order recorded from the reference."""
+    g = golden("g4_pghi_offline")
+    eps = np.float32(torch.finfo(torch.float32).eps)
+    for case in ("n12x17", "t12x17", "s12x17", "t40x65", "d40x65"):
+        mag = np.maximum(g[case + "_mag"].astype(np.float32), eps)
+        tol = np.float32(g[case + "_params"][2])
+        T, F = mag.shape
+        work = mag.copy()
+        order = []
+        heap = []
+        first = True
+        while True:
+            mx = work.max()
+            if first:
+                work[work < mx * tol] = eps                 # dgt.py:177-178, once, relative to the global maximum
+                first = False
+            if not (mx > eps):
+                break
+            t, f = np.argwhere(work == mx)[0]
+            work[t, f] = eps
+            A.heappush(heap, (-mx, (int(t), int(f))))
+            while heap:
+                _, (t, f) = A.heappop(heap)
+                order.append((t, f))
+                for (tt, ff) in ((t + 1, f), (t - 1, f), (t, f + 1), (t, f - 1)):
+                    if 0 <= tt < T and 0 <= ff < F and work[tt, ff] > eps:
+                        A.heappush(heap, (-work[tt, ff], (tt, ff)))
+                        work[tt, ff] = eps
+        assert np.array_equal(np.array(order).reshape(-1, 2), g[case + "_order"]), case
+    h = []
+    with pytest.raises(IndexError):
+        A.heappop(h)
+
+
+def test_double_precision_is_refused_not_narrowed():
+    """the reference's `dtype=torch.float64` keeps double buffers (stft.py:36-47); there is no fp64
+    kernel here, and computing in fp32 under that name would be a silent narrowing -- the constructors say so."""
+    for ctor in (A.STFT, A.DGT, A.RealtimeSTFT, A.RealtimeDGT, A.Magnitude):
+        with pytest.raises(A.AcidsHipError, match="float32"):
+            ctor(dtype=torch.float64)
+        ctor(dtype=torch.float32)

@@ -522,3 +522,18 @@ def test_c_abi_output_that_is_not_512_byte_aligned(dev, n):
     got = out.reshape(B, T, F)
     assert rel_max(cpu(torch.view_as_real(got)), cpu(torch.view_as_real(want))) < 2e-6
     assert complex(buf[0]) == 0j                              # nothing written in front of the output
+
+
+def test_float64_inputs_raise_instead_of_being_narrowed(dev):
+    """a float64 / complex128 operand is an error that names the way out, never a silent cast to fp32
+    (round 3 cast: `x.float()`); half and integer inputs are still widened."""
+    x = torch.randn(2, 8192, device=dev)
+    st = A.STFT().to(dev)
+    X = st(x)
+    for call in (lambda: st(x.double()), lambda: st.invert(X.to(torch.complex128)), lambda: st.invert(X.abs().double()),
+                 lambda: A.Magnitude(mode=None).to(dev)(X.to(torch.complex128)), lambda: A.DGT().to(dev)(x.double()),
+                 lambda: A.MFCC().to(dev)(x.double()), lambda: A.Phase(mode=None).to(dev)(X.to(torch.complex128)),
+                 lambda: A.RealtimeSTFT().to(dev)(x.double().reshape(2, 8, 1024))):
+        with pytest.raises(A.AcidsHipError, match="float64|complex128"):
+            call()
+    assert rel_max(cpu(st(x.half())), cpu(st(x.half().float()))) == 0.0

@@ -6,6 +6,10 @@ import torch
 import acids_transforms_amd as A
 
 which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["fwd", "inv", "mel128", "mel513"]
+# PERF_VARIANTS="epilogue=1,frame_kernels=1": kernel variants through the C ABI (at_set_variant); the library reads no environment
+for kv in filter(None, os.environ.get("PERF_VARIANTS", "").split(",")):
+    from acids_transforms_amd import _lib as _L
+    _L.check(_L.lib().at_set_variant(_L.VARIANTS[kv.split("=")[0]], int(kv.split("=")[1])), "at_set_variant")
 B, L = 1024, 176400
 dev = torch.device("cuda:0")
 x = torch.randn(B, L, device=dev) * 0.1
@@ -68,10 +72,16 @@ if "fused" in which or "fused2" in which or "fusedfeat" in which:
     if "fused2" in which:
         mf = A.MFCC().to(dev)   # features only: the spectrum never reaches HBM
         report("fwd+mel (no X)", timeit(lambda: mf(x)), 1024 + 512)
-if "fused513" in which:
+if "fused513" in which or "fused513feat" in which:
     mg5 = A.Magnitude().to(dev)            # reference default: 513-filter bank
     mg5.scale_data(X[:8])
-    report("fwd+mel513 fused", timeit(lambda: mg5.forward_fused(m, x, return_spectrum=True)), 1024 + 4104 + 2052)
+    if "fused513" in which:
+        report("fwd+mel513 fused", timeit(lambda: mg5.forward_fused(m, x, return_spectrum=True)), 1024 + 4104 + 2052)
+    if "fused513feat" in which:
+        from acids_transforms_amd import ops
+        off5, sc5 = mg5._affine()
+        report("fwd+mel513 feat-only", timeit(lambda: ops.stft_mel_forward(x, m.window[:1024], mg5._banded(), "log1p", off5, sc5,
+                                                                            mg5._eps, want_spectrum=False)), 1024 + 2052)
 if "fusedraw" in which:
     mgr = A.Magnitude(n_mels=128, mode=None, contrast=None).to(dev)
     report("fwd+mel raw", timeit(lambda: mgr.forward_fused(m, x, return_spectrum=True)), 5640)
