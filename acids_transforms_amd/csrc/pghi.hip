@@ -1073,7 +1073,18 @@ struct RtParams {
   int S, n, F, n_fft, hop;
   float gamma, tol, eps;
   int lds_floats_per_wave;  // cooperative kernel: LDS floats per stream (several streams per workgroup)
+  // rank fast path (pghi_rt_rank_kernel -> pghi_hgi_rt_coop_kernel): per (stream, new frame) the 2F candidates of the
+  // frame's flood -- rows f-1 and f -- sorted by magnitude: ent_of_rank[2F], rank_of_ent[2F] (u16 each), then one bit per
+  // rank: "same magnitude as the rank before".  Null: heap path only.
+  unsigned short* ranks;
+  long long rank_stride;    // u16 elements per (stream, frame) record
 };
+
+// one record: u16 ent_of_rank[2F], u16 rank_of_ent[2F], u32 same_as_previous[ceil(2F / 32)] (bit r: the magnitude at rank r
+// equals the one at rank r - 1), padded to 16 bytes
+__host__ __device__ inline long long rt_rank_stride_u16(int F) {
+  return ((8LL * F + 4LL * ((2 * F + 31) / 32) + 15) & ~15LL) / 2;
+}
 
 __device__ __forceinline__ float rt_mag(const RtParams& p, int s, int j, int k) {
   const float v = (j < 2) ? p.mag_hist[((long long)s * 2 + j) * p.F + k] : p.mag[((long long)s * p.n + (j - 2)) * p.F + k];
@@ -1363,6 +1374,54 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_lds_kernel(RtParams p) {
   }
 }
 
+// Rank pre-pass of the realtime flood.  A frame's flood (dgt.py:413-465) pops, in descending magnitude, entries that are
+// known before it starts: the bins of row f-1 (pushed up front) and the bins of row f (pushed as the flood reaches
+// them).  When no two of those magnitudes are equal, WHICH priority queue hands them out is immaterial -- the pop order
+// is the strict order of the keys -- and a bitmap over the ranks replaces the heap: pop = find-first-set, push = set a
+// bit.  Ranks are a sort, and a sort is parallel: one workgroup per (stream, frame) on the chip the one-wave-per-stream
+// flood leaves idle.  Equal magnitudes are marked per rank (`same_as_previous`); what the flood does about them is in
+// pghi_hgi_rt_coop_kernel.
+__global__ __launch_bounds__(256) void pghi_rt_rank_kernel(RtParams p, int n2) {
+  extern __shared__ __attribute__((aligned(16))) u64 rk_items[];
+  const int F = p.F, R = p.n + 2, E = 2 * F;
+  const int s = blockIdx.x / p.n, fr = blockIdx.x - s * p.n;          // new frame fr: rows fr + 1 (f - 1) and fr + 2 (f)
+  const float* rows = p.spec + ((long long)s * R + fr + 1) * F;       // 2F consecutive floats: row f-1, then row f
+  for (int i = threadIdx.x; i < n2; i += blockDim.x)
+    rk_items[i] = i < E ? (((u64)(~__float_as_uint(rows[i]))) << 32) | (unsigned)i : ~0ull;   // ascending = descending magnitude
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        const int x = i ^ j;
+        if (x > i) {
+          const u64 a = rk_items[i], b = rk_items[x];
+          if ((a > b) == ((i & k) == 0)) {
+            rk_items[i] = b;
+            rk_items[x] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  unsigned short* rec = p.ranks + ((long long)s * p.n + fr) * p.rank_stride;
+  unsigned* sp = reinterpret_cast<unsigned*>(rec + 2 * E);
+  for (int r = threadIdx.x; r < E; r += blockDim.x) {
+    const u64 it = rk_items[r];
+    const unsigned e = (unsigned)it & 0xffffu;
+    rec[r] = (unsigned short)e;
+    rec[E + e] = (unsigned short)r;
+  }
+  // same-as-previous bits, one thread per word (magnitudes are compared as the bit patterns they were sorted by)
+  for (int w = threadIdx.x; w < (E + 31) / 32; w += blockDim.x) {
+    unsigned bits = 0u;
+    for (int b = 0; b < 32; ++b) {
+      const int r = 32 * w + b;
+      if (r >= 1 && r < E && (unsigned)(rk_items[r] >> 32) == (unsigned)(rk_items[r - 1] >> 32)) bits |= 1u << b;
+    }
+    sp[w] = bits;
+  }
+}
+
 // The same frame step with the wave-cooperative heap of the offline kernel (coop_bubble / coop_siftdown), the
 // whole heap in LDS.  A frame pops up to 2F entries from a heap of ~1000: done by one lane that is ~10 dependent
 // LDS round trips down and a few up per pop (~3600 cycles); the cooperative pop resolves five levels per round
@@ -1432,7 +1491,175 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
     wave_argmax(max_val, max_k);
     max_val = ufloat(max_val);
     lds_sync();
-    if (max_val > abstol) {  // :416-417
+    // Rank fast path (see pghi_rt_rank_kernel): the frontier is a bitmap over the ranks of the frame's 2F candidates.
+    //
+    // Ties.  Among 1026 float32 magnitudes SOME two are equal in ~2 % of all frames -- with 256 streams in nearly every
+    // step -- so a tie cannot simply send the frame to the heap.  Tied entries leave the queue back to back in an order
+    // only the heap knows (its sift rules, utils/heapq.py:9-59).  Call a tied entry's pop together with everything that
+    // pops because of it before the next tied entry gets its turn (entries it pushes whose keys are larger) its BLOCK.
+    // A block's effect depends on the state only through the bins it looks at (its own phase, the availability of its
+    // targets): T; it changes the state only by visiting bins: V (subset of T).  If for every two blocks of a tie group
+    // V of one misses T of the other, every block does the same whatever order the group is taken in, and the result
+    // is the heap's.  That is checked as the group runs (in rank order); a collision abandons the fast path and the
+    // frame is redone on the heap.  (tools/fuzz_rt_ties.py: injected ties, bit for bit against the heap kernel.)
+    bool fast_done = false;
+    if (p.ranks != nullptr && max_val > abstol) {
+      const unsigned short* grec = p.ranks + ((long long)s * p.n + (f - 2)) * p.rank_stride;
+      // LDS: per-rank records where the heap would be (ONE ds_read_b128 per pop), the rank tables and two bitmaps behind
+      // them (the launcher sized the allocation for that).  A record is {phase, targets, step up, step down}:
+      //   row f-1, bin k:  {ph0[k],            rank of (f, k)   | 0xffff << 16,        0.5 (tg0[k] + tg1[k]),  0}
+      //   row f,   bin k:  {ph1[k] (written    rank of (f, k+1) | rank of (f, k-1) << 16, 0.5 (fg[k] + fg[k+1]), 0.5 (fg[k] + fg[k-1])}
+      //                     when reached),
+      // so that one pop is: target `up` gets phase + step up, target `down` gets phase - step down, whatever the row
+      // (dgt.py:438-440, 447-449, 455-457); 0xffff: no such target (k + 1 = F; k - 1 <= 0: bin 0 is never reached
+      // downward, :453).
+      // (an offset in floats, not a rounded address: a pointer that has been through uintptr_t is a generic pointer and
+      //  every access through it a flat_load / flat_store)
+      int4* recs = reinterpret_cast<int4*>(rt_smem + ((7 * F + 3) & ~3));         // [2F], 16-byte aligned (the wave's LDS is)
+      unsigned short* eor = reinterpret_cast<unsigned short*>(recs + 2 * F);     // entry at rank r (e < F: row f-1, bin e; else row f, bin e - F)
+      unsigned short* roe = eor + 2 * F;                                          // rank of entry e
+      unsigned* bm = reinterpret_cast<unsigned*>(roe + 2 * F);                    // [0,64): row f-1 live, [64,128): row f live, by rank
+      {
+        const unsigned* src = reinterpret_cast<const unsigned*>(grec);
+        unsigned* dst = reinterpret_cast<unsigned*>(eor);
+        for (int i = lane; i < 2 * F; i += 64) dst[i] = src[i];              // 4F u16 = 2F words
+        bm[lane] = 0u;
+        bm[64 + lane] = 0u;
+      }
+      const unsigned sp = (lane < (2 * F + 31) / 32) ? reinterpret_cast<const unsigned*>(grec + 4 * F)[lane] : 0u;   // same-as-previous, by rank
+      // rank r is part of a tie: same as its predecessor or as its successor (whose bit may sit in the next lane's word)
+      const unsigned tied_bits = sp | (sp >> 1) | ((unsigned)__shfl_down((int)sp, 1, 64) << 31);
+      lds_sync();
+      for (int k = lane; k < F; k += 64) {
+        const unsigned ra = roe[k], rb = roe[F + k];
+        if (hrow[k] > abstol) atomicOr(&bm[ra >> 5], 1u << (ra & 31));
+        if (srow[k] > abstol) atomicOr(&bm[64 + (rb >> 5)], 1u << (rb & 31));
+        recs[ra] = make_int4(__float_as_int(ph0[k]), (int)(rb | 0xffff0000u), __float_as_int(0.5f * (tg0[k] + tg1[k])), 0);
+        const unsigned ru = (k + 1 < F) ? (unsigned)roe[F + k + 1] : 0xffffu;
+        const unsigned rd = (k - 1 > 0) ? (unsigned)roe[F + k - 1] : 0xffffu;
+        const float gk = fg1[k];
+        recs[rb] = make_int4(__float_as_int(ph1[k]), (int)(ru | (rd << 16)), __float_as_int(0.5f * (gk + fg1[k + 1 < F ? k + 1 : k])),
+                             __float_as_int(0.5f * (gk + fg1[k >= 1 ? k - 1 : 0])));
+      }
+      lds_sync();
+      unsigned qbits = bm[lane];          // the frontier, by rank: lane i holds ranks 32 i .. 32 i + 31
+      unsigned bav = bm[64 + lane];       // row-f entries that are live and not yet visited, by rank
+      float* rec_phase = reinterpret_cast<float*>(recs);      // rec_phase[4 r] = phase of rank r
+      auto bit_of = [&](unsigned bits, int i) -> bool {
+        return (((unsigned)__builtin_amdgcn_readlane((int)bits, i >> 5)) >> (i & 31)) & 1u;
+      };
+      auto first_of = [&](unsigned bits, int& r) -> bool {       // lowest set rank of a lane-distributed bitmap
+        const u64 nz = __ballot(bits != 0u);
+        if (nz == 0) return false;
+        const int L = __builtin_ctzll(nz);
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)bits, L);
+        r = 32 * L + __builtin_ctz(w);
+        return true;
+      };
+      // tie-group state: cur_* = the running block, acc_* = the group's earlier blocks; T / V are sets of entries by rank
+      unsigned cur_v = 0u, cur_t = 0u, acc_v = 0u, acc_t = 0u;
+      // one pop of rank r (already off the frontier), its record in hand.  TRACK: inside a tie group, with the block
+      // bookkeeping.  Returns, for the caller's prefetch, whether rank `watch` had its phase written.
+      auto process = [&](int r, const int4 rec, int watch, auto track) -> bool {
+        constexpr bool TRACK = decltype(track)::value;
+        const unsigned w1 = (unsigned)uni(rec.y);
+        const int ru = (int)(w1 & 0xffffu), rd = (int)(w1 >> 16);
+        const float pk = __int_as_float(rec.x);
+        // availability of the two targets, without branching on "is there one": the lane index is masked, the verdict is not
+        const unsigned wu = (unsigned)__builtin_amdgcn_readlane((int)bav, (ru >> 5) & 63);
+        const unsigned wd = (unsigned)__builtin_amdgcn_readlane((int)bav, (rd >> 5) & 63);
+        const bool up = ru != 0xffff && ((wu >> (ru & 31)) & 1u);
+        const bool dn = rd != 0xffff && ((wd >> (rd & 31)) & 1u);
+        if (up && lane == 0) rec_phase[4 * ru] = pk + __int_as_float(rec.z);
+        if (dn && lane == 0) rec_phase[4 * rd] = pk - __int_as_float(rec.w);
+        const unsigned mu = up ? (1u << (ru & 31)) : 0u, md = dn ? (1u << (rd & 31)) : 0u;
+        const unsigned add = ((lane == (ru >> 5)) ? mu : 0u) | ((lane == (rd >> 5)) ? md : 0u);
+        qbits |= add;                       // the reached entries join the frontier ...
+        bav &= ~add;                        // ... and are no longer unvisited
+        if (TRACK) {
+          cur_v |= add;
+          cur_t |= add | ((lane == (r >> 5)) ? (1u << (r & 31)) : 0u) |
+                   ((ru != 0xffff && lane == (ru >> 5)) ? (1u << (ru & 31)) : 0u) |
+                   ((rd != 0xffff && lane == (rd >> 5)) ? (1u << (rd & 31)) : 0u);
+        }
+        return (up && ru == watch) || (dn && rd == watch);
+      };
+      auto close_block = [&]() -> bool {    // the running block against the group's earlier ones; then it joins them
+        const bool clash = __ballot(((cur_v & acc_t) | (cur_t & acc_v)) != 0u) != 0;
+        acc_v |= cur_v;
+        acc_t |= cur_t;
+        cur_v = 0u;
+        cur_t = 0u;
+        return !clash;
+      };
+      bool ok = true;
+      int r = 0;
+      if (first_of(bav, r)) {               // :427 the frame maximum seeds the frontier and is NOT marked visited
+        if (lane == (r >> 5)) qbits |= 1u << (r & 31);
+      }
+      while (true) {
+        // ---- the common case: pops whose magnitude is nobody else's
+        // (Requesting the next pop's record ahead -- the frontier's next rank as it stands, read again when this pop reaches
+        //  something larger -- was built and measured: 0.26 -> 0.39 ms per frame; the select between the two records and
+        //  the extra find-first cost more than the round trip they hide.)
+        bool tied = false;
+        while (first_of(qbits, r)) {
+          if (bit_of(tied_bits, r)) {
+            tied = true;
+            break;
+          }
+          if (lane == (r >> 5)) qbits &= ~(1u << (r & 31));
+          process(r, recs[r], -1, std::integral_constant<bool, false>());
+        }
+        if (!tied) {                        // :461-465 the frontier ran dry: the largest unvisited bin of the row, marked
+          if (!first_of(bav, r)) break;     // (the reference pushes one last entry at or below abstol and leaves: no effect)
+          if (lane == (r >> 5)) {
+            bav &= ~(1u << (r & 31));
+            qbits |= 1u << (r & 31);        // popped at once by the next trip
+          }
+          continue;
+        }
+        // ---- a tie group: ranks [g_lo, g_hi] share one magnitude; rank r, still on the frontier, is its first member out
+        int g_lo = r, g_hi = r;
+        while (bit_of(sp, g_lo)) --g_lo;                                  // (bit 0 is never set)
+        while (g_hi + 1 < 2 * F && bit_of(sp, g_hi + 1)) ++g_hi;
+        cur_v = cur_t = acc_v = acc_t = 0u;
+        bool finished = false;
+        while (true) {
+          if (!first_of(qbits, r)) {        // reseed inside the group's span: part of the running block
+            if (!first_of(bav, r)) {
+              finished = true;
+              break;
+            }
+            if (lane == (r >> 5)) {
+              bav &= ~(1u << (r & 31));
+              qbits |= 1u << (r & 31);
+              cur_v |= 1u << (r & 31);
+              cur_t |= 1u << (r & 31);
+            }
+            continue;
+          }
+          if (r > g_hi) break;              // the group is over; rank r stays on the frontier for the common loop
+          if (lane == (r >> 5)) qbits &= ~(1u << (r & 31));
+          if (r >= g_lo && !close_block()) {       // the next tied entry: the running block is complete
+            ok = false;
+            break;
+          }
+          process(r, recs[r], -1, std::integral_constant<bool, true>());
+        }
+        if (ok && !close_block()) ok = false;
+        if (!ok || finished) break;
+      }
+      fast_done = ok;
+      lds_sync();
+      if (ok) {                             // back to bin order
+        for (int k = lane; k < F; k += 64) ph1[k] = rec_phase[4 * roe[F + k]];
+        lds_sync();
+      }
+    }
+    if (fast_done) {
+      // nothing left to do for this frame
+    } else if (max_val > abstol) {  // :416-417
       int hn = 1;
       if (lane == 0) H.store(0, pack_item(-max_val, F + (int)max_k));   // :427 the seed is NOT marked visited
       lds_sync();
@@ -1714,8 +1941,9 @@ extern "C" {
 
 size_t at_pghi_rt_workspace_bytes(int S, int n, int F) {
   const size_t per = (size_t)(n + 2) * (size_t)F;
-  // spec, hist, tgradw, fgradw, phase (n + 2 rows each) + device-drawn noise (n rows) + heap
-  return (size_t)S * (6 * per * sizeof(float) + (4 * (size_t)F + 8) * sizeof(HeapItem)) + 256;
+  // spec, hist, tgradw, fgradw, phase (n + 2 rows each) + device-drawn noise (n rows) + heap + the rank records
+  return (size_t)S * (6 * per * sizeof(float) + (4 * (size_t)F + 8) * sizeof(HeapItem) +
+                      (size_t)n * (size_t)at_hip::rt_rank_stride_u16(F) * 2) + 512;
 }
 
 static int pghi_realtime_impl(const float* mag_hist, const float* mag, const float* prev_phase, const float* noise,
@@ -1741,13 +1969,29 @@ static int pghi_realtime_impl(const float* mag_hist, const float* mag, const flo
   uintptr_t hp = ((uintptr_t)(w + 6 * (size_t)S * per) + 15) & ~(uintptr_t)15;
   p.heap = (HeapItem*)hp;
   p.S = S; p.n = n; p.F = F; p.n_fft = n_fft; p.hop = hop; p.gamma = gamma; p.tol = tol; p.eps = eps;
+  p.ranks = nullptr;
+  p.rank_stride = rt_rank_stride_u16(F);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pghi_grad_rt_kernel, dim3(grid1d((long long)S * per)), dim3(256), 0, s, p);
   const size_t lds = sizeof(float) * (7 * (size_t)F + 1) + sizeof(HeapItem) * (4 * (size_t)F + 8);
-  // at_set_variant(AT_VARIANT_PGHI_KERNEL, 2) selects the single-lane kernels (debugging aid; identical results)
-  const bool serial_rt = variant(kVarPghiKernel) == 2;
+  // at_set_variant(AT_VARIANT_PGHI_KERNEL, 2) selects the single-lane kernels (debugging aid; identical results), 3 the
+  // cooperative heap kernel without the rank fast path
+  const int pghi_kernel = variant(kVarPghiKernel);
+  const bool serial_rt = pghi_kernel == 2;
+  // the fast path keeps 2F 16-byte records where the heap would be and 8F + 512 bytes of tables behind them
+  const size_t lds_fast = sizeof(float) * (7 * (size_t)F + 4) + 16 * (2 * (size_t)F) + 8 * (size_t)F + 512 + 16;
+  bool rank_path = false;
+  if (lds_fast <= 64 * 1024 && !serial_rt && pghi_kernel != 3 && 2 * F <= 2048 && F >= 8 && (long long)S * n < (1LL << 31)) {
+    rank_path = true;
+    // rank pre-pass: one workgroup per (stream, new frame) sorts the frame's 2F candidates
+    uintptr_t rp = ((uintptr_t)(p.heap + (size_t)S * (4 * (size_t)F + 8)) + 15) & ~(uintptr_t)15;
+    p.ranks = (unsigned short*)rp;
+    int n2 = 2;
+    while (n2 < 2 * F) n2 <<= 1;
+    hipLaunchKernelGGL(pghi_rt_rank_kernel, dim3((unsigned)((long long)S * n)), dim3(256), (size_t)n2 * sizeof(u64), s, p, n2);
+  }
   if (lds <= 64 * 1024 && !serial_rt) {
-    const size_t per_wave = (lds + 15) & ~(size_t)15;
+    const size_t per_wave = ((rank_path ? (lds_fast > lds ? lds_fast : lds) : lds) + 15) & ~(size_t)15;
     // up to one stream per CU spreads best (256 streams: 3.5 ms alone on their CUs, 3.7 ms packed four to a CU);
     // from four per CU on, a workgroup of four loads the CU's SIMDs evenly (1024 streams: 4.15 -> 3.88 ms)
     int wpb = S >= 4 * 256 ? 4 : 1;

@@ -17,7 +17,8 @@ enum {
   kVarFrameKernels = 1,     // 1: frame-at-a-time forward at n_fft 512 / 2048 / 4096 instead of the sliding-window kernels
   kVarSmallProjection = 2,  // 0: matrix-core form of the K <= 128 projection (the DCT behind MFCC); 1: row kernel
   kVarScanLayout = 3,       // 0: one block per clip for rows that are not whole 64-byte segments; 1: flattened columns
-  kVarPghiKernel = 4,       // 0: cooperative heap kernels; 1: winner-bit offline kernel; 2: single-lane kernels
+  kVarPghiKernel = 4,       // 0: cooperative heap kernels (+ rank fast path, realtime); 1: winner-bit offline kernel;
+                            // 2: single-lane kernels; 3: cooperative kernels, realtime without the rank fast path
   kVarCount = 5
 };
 

@@ -50,7 +50,8 @@ const char *at_error_string(int code);
 #define AT_VARIANT_FRAME_KERNELS 1     /* 1: frame-at-a-time forward at n_fft 512 / 2048 / 4096 (no sliding window) */
 #define AT_VARIANT_SMALL_PROJECTION 2  /* 1: row kernel instead of the matrix-core form of the K <= 128 projection */
 #define AT_VARIANT_SCAN_LAYOUT 3       /* 1: flattened columns instead of one block per clip in the phase scans */
-#define AT_VARIANT_PGHI_KERNEL 4       /* 1: winner-bit offline heap kernel; 2: single-lane heap kernels */
+#define AT_VARIANT_PGHI_KERNEL 4       /* 1: winner-bit offline heap kernel; 2: single-lane heap kernels; 3: realtime
+                                        * flood on the heap even where the rank fast path applies */
 int at_set_variant(int which, int value);
 int at_get_variant(int which);
 

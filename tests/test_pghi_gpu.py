@@ -12,6 +12,7 @@ import torch
 import acids_transforms_amd as A
 from acids_transforms_amd import ops
 from conftest import rel_max
+from acids_transforms_amd._lib import variant
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -346,3 +347,55 @@ def test_direct_pghi_calls_use_the_reference_defaults(dev):
     m = mag[:4].unsqueeze(0)
     z = torch.zeros_like(m)
     assert torch.equal(rt.pghi(m, noise=z), rt.pghi(m, 1e-6, noise=z))
+
+
+@pytest.mark.parametrize("n_fft,hop,S,n", [(1024, 256, 5, 3), (1024, 256, 3, 1), (512, 128, 4, 4), (400, 160, 3, 2), (256, 64, 2, 5),
+                                            (2048, 512, 2, 2), (64, 16, 3, 3)])
+def test_realtime_rank_fast_path_equals_the_heap_kernels(dev, n_fft, hop, S, n):
+    """Round 4: where no two candidate magnitudes of a frame are equal, the realtime flood hands its entries out through a
+    bitmap over their ranks (sorted by a pre-pass) instead of the heap.  Same pop order, same float operations: the
+    phases must be the SAME BITS as the cooperative heap kernel's (variant 3) and the single-lane kernel's (variant 2), on
+    noise, on sparse spectra (reseeds inside a frame, bins below the tolerance) and on input with exact ties -- quantised
+    magnitudes, and a frame repeated exactly (every candidate of row f ties with row f-1) -- where the pre-pass reports
+    the tie and the frame takes the heap.  n_fft 2048 (2F > 2048) and 64 (tables do not fit) never take the fast path."""
+    F = n_fft // 2 + 1
+    g = torch.Generator().manual_seed(n_fft + 7 * S + n)
+    rt = A.RealtimeDGT(n_fft=n_fft, hop_length=hop, batch_size=[S]).to(dev)
+    kinds = {}
+    base = (torch.randn(S, n + 2, F, generator=g) ** 2 + torch.randn(S, n + 2, F, generator=g) ** 2).sqrt()
+    kinds["noise"] = base
+    kinds["sparse"] = base * (torch.rand(S, n + 2, F, generator=g) < 0.15) + 1e-6
+    kinds["quantised"] = torch.round(base * 3) / 3 + 0.25
+    rep = base.clone()
+    rep[:, 1:] = rep[:, :1]                                          # every frame equal to the one before
+    kinds["repeated"] = rep
+    peaky = base * torch.exp(-((torch.arange(F) - F / 3.0) / (F / 20.0)) ** 2)      # most bins under the tolerance
+    kinds["peaky"] = peaky + 1e-7
+    for kind, m in kinds.items():
+        hist, mag = m[:, :2].contiguous().to(dev), m[:, 2:].contiguous().to(dev)
+        prev = (torch.rand(S, F, generator=g) * 6.28).to(dev)
+        noise = torch.randn(S, n, F, generator=g).to(dev)
+        args = (float(rt.gamma), n_fft, hop, float(rt.tolerance), float(rt.eps))
+        got = ops.pghi_realtime(hist, mag, prev, noise, *args)
+        with variant("pghi_kernel", 3):
+            heap = ops.pghi_realtime(hist, mag, prev, noise, *args)
+        with variant("pghi_kernel", 2):
+            serial = ops.pghi_realtime(hist, mag, prev, noise, *args)
+        assert torch.equal(got, heap), (kind, float((got - heap).abs().max()))
+        assert torch.equal(got, serial), (kind, float((got - serial).abs().max()))
+        assert bool(torch.isfinite(got).all())
+
+
+def test_realtime_rank_fast_path_with_injected_ties(dev):
+    """tools/fuzz_rt_ties.py: magnitudes copied onto other bins (far away: the tied pops commute and the frame stays on the
+    bitmap; next to each other or onto the frame maximum: the blocks collide and the frame is redone on the heap) --
+    the phases are the cooperative heap kernel's bit for bit either way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_CASES="80", FUZZ_SEED="11")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_rt_ties.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "80 cases ok" in r.stdout and "bit for bit" in r.stdout
