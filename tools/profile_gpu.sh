@@ -3,7 +3,7 @@
 # usage: tools/profile_gpu.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 20 --warmup 5 --no-cpu-baseline --no-extras}
+ARGS=${@:---steps 20 --warmup 5 --settle-steps 60 --no-cpu-baseline --no-extras}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -23,7 +23,7 @@ def short(name):
 
 print("# rocprofv3 summary `%s`\n" % tag)
 STEPS, WARM = int(os.environ.get("PROFILE_STEPS", "20")), int(os.environ.get("PROFILE_WARMUP", "5"))
-SETTLE = int(os.environ.get("PROFILE_SETTLE", "40"))          # bench.py --settle-steps (untimed, before the warm-up steps)
+SETTLE = int(os.environ.get("PROFILE_SETTLE", "60"))          # bench.py --settle-steps (untimed, before the warm-up steps)
 print("Command: `python3 bench.py --steps %d --warmup %d --no-cpu-baseline --no-extras` (B=1024 clips x 4 s, 1 GPU; "
       "%d settle steps before the warm-up)\n" % (STEPS, WARM, SETTLE))
 WARM += SETTLE
@@ -73,7 +73,7 @@ if traffic:
     # what bench.py reports as roofline.traffic: per-launch HBM bytes of the step kernels from THIS pass
     bt = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `%s`; FETCH_SIZE "
                       "doubled per MI355X_MICROARCH.md (gfx950)" % tag}
-    for key, needle in (("stft_fwd", "stft1024_h256_fwd_kernel<false, 1"), ("stft_fwd_unfused", "stft1024_h256_fwd_kernel<false, 0"),
+    for key, needle in (("stft_fwd", "stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2"), ("stft_fwd_unfused", "stft1024_h256_fwd_kernel<false, 0"),
                         ("istft", "istft1024_ola_kernel"), ("mel", "mel_banded_kernel")):
         for k, v in js.items():
             if needle in k:
