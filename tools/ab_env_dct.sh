@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 4: the switches exist only in the DEVELOPMENT build of the library -- tools/README.md -- load it with
+#  ACIDS_HIP_LIB=tools/ab/libacids_dev.so)
 # A/B of the small projection's forms on one box: tools/ab_env_dct.sh [rounds]
 for i in $(seq 1 ${1:-2}); do
   for f in regs regs_nt lds lds_nt; do
