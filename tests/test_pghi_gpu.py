@@ -384,6 +384,10 @@ def test_realtime_rank_fast_path_equals_the_heap_kernels(dev, n_fft, hop, S, n):
         assert torch.equal(got, heap), (kind, float((got - heap).abs().max()))
         assert torch.equal(got, serial), (kind, float((got - serial).abs().max()))
         assert bool(torch.isfinite(got).all())
+        if kind in ("noise", "sparse"):          # and the checker itself: the C restatement of dgt.py:330-466
+            ref = O.pghi_realtime(hist.cpu().numpy(), mag.cpu().numpy(), prev.cpu().numpy(), noise.cpu().numpy(), n_fft, hop,
+                                  tol=float(rt.tolerance), gamma=float(rt.gamma), eps=float(rt.eps))["phase"]
+            assert np.all(np.abs(cpu(got) - ref) <= phase_tol(ref, base=2e-3, ulps=16)), kind
 
 
 def test_realtime_rank_fast_path_with_injected_ties(dev):
