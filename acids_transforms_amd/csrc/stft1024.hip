@@ -228,14 +228,18 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   constexpr int kNP = FQP ? FNP : 1;
   constexpr int kPkStride = (kNP + 3) / 4 * 4;       // dwords per lane in the packed descriptor table (16-byte rows)
   constexpr int kTabTw = TWLDS ? kTwiddleCount : 0;
-  __shared__ float2 lds_all[FWD_WAVES * kFftLdsFloat2PerWave + kTabTw + 512];
+  // FQP kernels: 1 KB per wave IN FRONT of its FFT slab -- the floats of the feature stream that are carried into the
+  // next frame's first aligned block (the slab itself is rewritten by every transform)
+  constexpr int kFeatCarry = FQP ? 128 : 0;               // float2
+  constexpr int kWaveLds = kFftLdsFloat2PerWave + kFeatCarry;
+  __shared__ float2 lds_all[FWD_WAVES * kWaveLds + kTabTw + 512];
   extern __shared__ float4 band_lds[];   // MEL != 0: the bank's weight table, sized by the launcher
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction; said explicitly, or everything derived from it (clip, run bounds, the frame
   // counter of the main loop, the column rotation) lives in vector registers and the loop control runs on the VALU
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
-  float2* tab = lds_all + FWD_WAVES * kFftLdsFloat2PerWave;
+  float2* lds = lds_all + wave * kWaveLds + kFeatCarry;
+  float2* tab = lds_all + FWD_WAVES * kWaveLds;
   // workgroup-shared constants: (twiddle table,) analysis window, band weights
   if (TWLDS)
     for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * FWD_WAVES) tab[i] = twiddle_for_lds<false>(p.tw, i);
@@ -341,6 +345,17 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   const long long phase_ld = (POLAR && p.phase_ld) ? p.phase_ld : F;
   float* prow = (WRITE_PHASE || POLAR) ? p.phase + (b * p.T + t0) * phase_ld : nullptr;
   float* frow = (MEL != 0) ? p.feat + (b * p.T + t0) * feat_ld : nullptr;
+  // FQP: the features leave as ONE stream of 1-KB aligned blocks too ((B, T, 513) floats are contiguous; a row is 2052
+  // bytes): fc floats of the current block are already in hand (carried in LDS), fdst is that block, fhead the number of
+  // leading floats of the run's first block that belong to the run before it
+  int fc = 0, fhead = 0;
+  float* fdst = nullptr;
+  if constexpr (FQP != 0) {
+    const long long fe0 = (b * p.T + t0) * (long long)F;
+    fc = (int)(fe0 & 255);
+    fhead = fc;
+    fdst = p.feat + (fe0 - fc);
+  }
   float ph_off = 0.f, ph_sc = 1.f;
   if (POLAR && p.ph_offset) {
     ph_off = *p.ph_offset;
@@ -561,9 +576,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
       // The lanes of a pass hold filters scattered over the whole row (passes are cut by band length, lanes placed for
       // conflict-free magnitude reads): stored straight from the lanes, each pass is a 64-lane scatter of 4-byte stores
       // over ~30 different 64-byte segments -- ~270 write requests per frame for 2 KB of features, more than the 4 KB
-      // spectrum row costs.  The row is put in order through the LDS slab instead (the magnitudes are dead once every
-      // walk is done) and leaves as two 1-KB stores and the last bin.
+      // spectrum row costs.  The row is put in order through LDS instead (the magnitudes are dead once every walk is
+      // done), BEHIND the fc floats carried from the frame before, and whole 1-KB aligned blocks of the feature stream
+      // leave: 32 write requests per frame (two 1-KB stores at the row's own 4-byte-aligned base were 51: a lane's 16
+      // bytes straddle a 64-byte boundary on three rows of four) -- the spectrum-storing form is bound by exactly that
+      // count (profiles/r04_default_bank_513.md).
       wave_lds_sync();
+      float* fbuf = reinterpret_cast<float*>(lds) - 2 * kFeatCarry;      // [0, 256): carried floats; [256, ..): the FFT slab
 #pragma unroll
       for (int g = 0; g < kPkStride / 4; ++g) {
         const int4 d = pk4[g];        // read again rather than held across the walk
@@ -573,19 +592,32 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
           if (4 * g + k < kNP) {
             const float fv = (band_contrast_fast(sums[4 * g + k], 1, p.eps) - mel_off) * mel_inv;
             const int f_off = (int)((unsigned)dd[k] >> 12);
-            if (f_off != 0xfff) *reinterpret_cast<float*>(reinterpret_cast<char*>(absrow) + f_off) = fv;
+            if (f_off != 0xfff) *reinterpret_cast<float*>(reinterpret_cast<char*>(fbuf + fc) + f_off) = fv;
           }
         }
       }
       wave_lds_sync();
-      // two 1-KB stores (16 bytes per lane; rows start on 4-byte boundaries, which dwordx4 stores accept) and the last bin
       {
-        const float4 r0 = reinterpret_cast<const float4*>(absrow)[lane];
-        const float4 r1 = reinterpret_cast<const float4*>(absrow)[64 + lane];
-        float* dst = frow + 4 * lane;
-        __builtin_memcpy(dst, &r0, 16);
-        __builtin_memcpy(dst + 256, &r1, 16);
-        if (lane == 0) frow[512] = absrow[512];
+        const int n = fc + F;             // floats in hand: two or three whole blocks and a remainder
+        const int nblk = n >> 8;
+        const float4* fb4 = reinterpret_cast<const float4*>(fbuf);
+        if (fhead > 0) {                  // the run's first block: its leading fhead floats are another run's
+          const float4 v = fb4[lane];
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (4 * lane + c >= fhead) fdst[4 * lane + c] = vv[c];
+        } else {
+          *reinterpret_cast<float4*>(fdst + 4 * lane) = fb4[lane];
+        }
+        fhead = 0;
+        *reinterpret_cast<float4*>(fdst + 256 + 4 * lane) = fb4[64 + lane];
+        if (nblk == 3) *reinterpret_cast<float4*>(fdst + 512 + 4 * lane) = fb4[128 + lane];
+        const float4 rem = fb4[64 * nblk + lane];       // the remainder moves to the front (junk behind it is overwritten)
+        wave_lds_sync();
+        reinterpret_cast<float4*>(fbuf)[lane] = rem;
+        fc = n & 255;
+        fdst += 256 * nblk;
       }
       wave_lds_sync();
       frow += feat_ld;
@@ -704,6 +736,16 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   flush_nyquist();
   if constexpr (AL) {
     if (lane < rot) put(sp, carry);      // the run's last block: the next run (or clip) owns the rest of it
+  }
+  if constexpr (FQP != 0) {              // likewise the feature stream's last, partial block
+    wave_lds_sync();
+    const float* fbuf = reinterpret_cast<const float*>(lds) - 2 * kFeatCarry;
+    const float4 v = reinterpret_cast<const float4*>(fbuf)[lane];
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (4 * lane + c < fc && 4 * lane + c >= fhead) fdst[4 * lane + c] = vv[c];
+    wave_lds_sync();
   }
   };   // do_run
 
@@ -1216,12 +1258,14 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
       fq_logpow = true;
     }
     // The reference's default bank -- Magnitude() at sr 44100: 404 non-empty filters of 513 in seven passes of 3, 2, 2, 1,
-    // 1, 1, 1 quads -- with log1p and |X|: the packed fixed-length epilogue (the generic one spends ~125 instructions per
-    // pass on run-time switches around a walk of one to three quads)
-    if (hop == 256 && !polar && !phase && !feat_channel_major && contrast == 1 && !power2 && bank_is(bank, kDefaultBankQuads, kDefaultBankPasses) &&
-        variant(kVarEpilogue) == 0) {
-      kernel = out ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 0, 0, 0, false, false, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>
-                   : stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 0, 0, 0, false, false, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>;
+    // 1, 1, 1 quads (and two of empty filters) -- with log1p and |X|, FEATURES ONLY (the README chain's forward): the
+    // packed fixed-length epilogue, 0.92 -> 0.78-0.84 ms per 1024 clips.  The spectrum-storing form keeps the generic
+    // epilogue: it is bound by the memory system's rate for one read and two write streams (~4.1 TB/s), and neither fewer
+    // instructions (-31 %) nor fewer write requests (115 -> 96 per frame) nor aligned spectrum blocks moved it
+    // (1.25-1.34 ms in every combination, same boxes: profiles/r04_default_bank_513.md).
+    if (hop == 256 && !polar && !phase && !feat_channel_major && !out && contrast == 1 && !power2 &&
+        bank_is(bank, kDefaultBankQuads, kDefaultBankPasses) && (((uintptr_t)feat) & 15) == 0 && variant(kVarEpilogue) == 0) {
+      kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 0, 0, 0, false, false, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>;
       default_bank_fixed = true;
     }
     if (hop == 128) {
@@ -1256,10 +1300,6 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
         kernel = stft1024_h256_fwd_kernel<false, 0, 8, true, 0, false, 2, 0, 0, 0, true, true, 0, 1, false, true>;
         persistent = true;
       }
-    } else if (al_ok && default_bank_fixed && out) {
-      kernel = store_mode == 1
-                   ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 0, 0, 0, true, false, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>
-                   : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 0, 0, 0, true, true, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>;
     } else if (al_ok && kernel == (void (*)(FwdRunParams))stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2>) {
       kernel = store_mode == 1 ? stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, false>
                                : stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, true>;
