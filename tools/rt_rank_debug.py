@@ -1,4 +1,5 @@
-"""Dev: dump the tie keys the realtime rank pre-pass reports per (stream, frame)."""
+"""Dev: check the rank records of the realtime pre-pass per (stream, frame): sort order, inverse table, the number of
+"same magnitude as the rank before" bits."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
@@ -26,7 +27,7 @@ per = (n + 2) * F
 base = ws.data_ptr()
 heap_off = ((base + 6 * S * per * 4 + 15) & ~15) - base
 rank_off = ((base + heap_off + S * (4 * F + 8) * 8 + 15) & ~15) - base
-stride_b = ((8 * F + 4 + 15) & ~15)
+stride_b = ((8 * F + 4 * ((2 * F + 31) // 32) + 15) & ~15)
 smax = float(m.max())
 print("abstol", 1e-2 * smax, "tolerance", float(rt.tolerance))
 for s in range(S):
@@ -34,7 +35,8 @@ for s in range(S):
         rec = raw[rank_off + (s * n + fr) * stride_b:][:stride_b]
         eor = rec[:4 * F].view(np.uint16)[:2 * F]
         roe = rec[4 * F:8 * F].view(np.uint16)
-        tie = rec[8 * F:8 * F + 4].view(np.float32)[0]
+        sp = rec[8 * F:8 * F + 4 * ((2 * F + 31) // 32)].view(np.uint32)
+        tie = int(sum(bin(int(w)).count("1") for w in sp))
         rows = m[s, fr + 1:fr + 3].reshape(-1).numpy()
         order_ok = np.array_equal(np.argsort(-rows, kind="stable"), eor.astype(np.int64))
-        print(s, fr, "tie_key", tie, "sorted ok", order_ok, "roe ok", np.array_equal(roe[eor], np.arange(2 * F)))
+        print(s, fr, "tied ranks", tie, "sorted ok", order_ok, "roe ok", np.array_equal(roe[eor], np.arange(2 * F)))
