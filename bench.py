@@ -1083,6 +1083,12 @@ def main():
                           "note": "per-step kernel time (HIP events) inside the timed region: flat = steady state"},
     }
     result.update(extras)
+    if "hbm_probe" in extras:
+        # the pool's boxes differ by up to 9 % on the step kernels and that spread follows what each box gives a MIXED
+        # read / write stream (torch copy_: 4.77 ... 5.07 TB/s), not its write-only or read-only rate (fill_ / sum: equal
+        # on all of them): the achieved rate next to the same box's copy_, for comparing runs across boxes
+        roof["achieved_vs_box_copy"] = round(roof["achieved"] / extras["hbm_probe"]["copy_GBps"], 4)
+        roof["box_copy_GBps"] = extras["hbm_probe"]["copy_GBps"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         hc = host_cpus()
         result["host_cpus"] = hc
