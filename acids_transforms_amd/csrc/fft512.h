@@ -228,6 +228,43 @@ __device__ __forceinline__ void load_twiddles(Twiddles& tw, const float2* __rest
 // ends up with Z[out_lane + 64 m].  The second exchange reads through it, so any permutation of the 64 output
 // columns over the lanes is free (a rotation keeps the reads conflict-free: 32 consecutive lanes still cover 32
 // consecutive 8-byte slots modulo a multiple of 256 bytes).
+// AT_XCHG1_SWAP: 1 (default) = the forward transforms take their first exchange through registers (same-box A/B, 1024
+// clips: plain forward 0.762 -> 0.758 ms, fused 0.884 -> 0.876, features only 0.616 -> 0.602; the inverse 0.722 -> 0.726,
+// so it keeps the LDS exchange); 0 = LDS for both; 2 = registers for both
+#ifndef AT_XCHG1_SWAP
+#define AT_XCHG1_SWAP 1
+#endif
+__device__ __forceinline__ void xchg1_registers(v2f (&v)[8]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)             // register bit 2 <-> lane bit 5
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k][c]), __float_as_uint(v[k + 4][c]), false, false);
+      v[k][c] = __uint_as_float(sw[0]);
+      v[k + 4][c] = __uint_as_float(sw[1]);
+    }
+#pragma unroll
+  for (int g = 0; g < 8; g += 4)          // register bit 1 <-> lane bit 4
+#pragma unroll
+    for (int k = g; k < g + 2; ++k)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[k][c]), __float_as_uint(v[k + 2][c]), false, false);
+        v[k][c] = __uint_as_float(sw[0]);
+        v[k + 2][c] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+  for (int k = 0; k < 8; k += 2)          // register bit 0 <-> lane bit 3: row_ror:8 swaps the halves of a 16-lane row
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int a = __float_as_int(v[k][c]), b = __float_as_int(v[k + 1][c]);
+      const int a2 = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xc, false);     // lanes 8..15 of each row take b[lane ^ 8]
+      const int b2 = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false);     // lanes 0..7 take a[lane ^ 8]
+      v[k][c] = __int_as_float(a2);
+      v[k + 1][c] = __int_as_float(b2);
+    }
+}
+
 template <bool INV, typename TW>
 __device__ __forceinline__ void fft512(v2f (&v)[8], const TW& tw, float2* lds_f2, int lane, int out_lane = -1) {
   if (out_lane < 0) out_lane = lane;
@@ -236,13 +273,20 @@ __device__ __forceinline__ void fft512(v2f (&v)[8], const TW& tw, float2* lds_f2
   radix8<INV>(v);
 #pragma unroll
   for (int k = 1; k < 8; ++k) v[k] = twiddle<INV>(v[k], tw.get1(k - 1));
-  // xchg 1: writer (n0=lo, n1=hi), element k0 -> index n1*72 + n0 + 8*k0
+  if constexpr (AT_XCHG1_SWAP == 2 || (AT_XCHG1_SWAP == 1 && !INV)) {
+    // xchg 1 in registers: the transpose (register index) <-> (lane bits 3..5) as three bit swaps -- v_permlane32_swap
+    // (lane bit 5 with register bit 2), v_permlane16_swap (lane bit 4, register bit 1), and two masked DPP row rotations
+    // by 8 (lane bit 3, register bit 0) -- 32 instructions instead of 4 ds_write2_b64 + 8 ds_read_b64 + two waits
+    xchg1_registers(v);
+  } else {
+    // xchg 1: writer (n0=lo, n1=hi), element k0 -> index n1*72 + n0 + 8*k0
 #pragma unroll
-  for (int k = 0; k < 8; ++k) lds[hi * 72 + lo + 8 * k] = v[k];
-  wave_lds_sync();
+    for (int k = 0; k < 8; ++k) lds[hi * 72 + lo + 8 * k] = v[k];
+    wave_lds_sync();
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = lds_read_single(lds + k * 72 + lane);
-  wave_lds_sync();
+    for (int k = 0; k < 8; ++k) v[k] = lds_read_single(lds + k * 72 + lane);
+    wave_lds_sync();
+  }
   radix8<INV>(v);
 #pragma unroll
   for (int k = 1; k < 8; ++k) v[k] = twiddle<INV>(v[k], tw.get2(k - 1));
@@ -259,7 +303,9 @@ __device__ __forceinline__ void fft512(v2f (&v)[8], const TW& tw, float2* lds_f2
 // float 639 over zero weights WITHOUT clearing floats 513..639 first: correct only while those floats -- float2 slots
 // 256..319 -- hold finite leftovers of the SAME frame, i.e. while the two exchanges above rewrite every one of them in
 // every transform (0 x Inf would be NaN, stale values of an earlier frame might be anything).  Pinned here, next to the
-// strides it depends on.
+// strides it depends on.  With the first exchange in registers (AT_XCHG1_SWAP, the forward default since round
+// 4) only the second one rewrites the slab and slots 262-263 are never reached: the kernels with a fixed-length epilogue
+// clear floats 512..639 of the slab once, at their start (stft1024.hip), and everything written there afterwards is finite.
 constexpr bool fft512_exchanges_cover(int lo_slot, int hi_slot) {
   for (int s = lo_slot; s <= hi_slot; ++s) {
     bool hit = false;
@@ -271,7 +317,7 @@ constexpr bool fft512_exchanges_cover(int lo_slot, int hi_slot) {
   }
   return true;
 }
-static_assert(fft512_exchanges_cover(256, 319) && 320 <= kFftLdsFloat2PerWave,
+static_assert(AT_XCHG1_SWAP || (fft512_exchanges_cover(256, 319) && 320 <= kFftLdsFloat2PerWave),
               "the fixed-length mel epilogue reads absrow[513..639] uncleared: both exchanges must rewrite float2 slots 256..319");
 
 template <bool INV, typename TW>

@@ -280,6 +280,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   // profiles/r04_launch_shape.md).
   __shared__ unsigned s_tile[2];
   if (PW && threadIdx.x == 0) s_tile[0] = atomicAdd(p.tile_ctr, 1u);
+#if AT_XCHG1_SWAP
+  // with the first exchange in registers only the second one rewrites the slab: the floats behind bin 512 that it does not
+  // reach must be finite for the fixed-length epilogues (fft512.h) -- cleared once
+  if (MEL != 0) {
+    reinterpret_cast<float*>(lds)[512 + lane] = 0.0f;
+    reinterpret_cast<float*>(lds)[576 + lane] = 0.0f;
+  }
+#endif
   __syncthreads();
 
   int sp_f[SP > 0 ? SP : 1], sp_start[SP > 0 ? SP : 1], sp_quads[SP > 0 ? SP : 1];
