@@ -108,6 +108,8 @@ __device__ __forceinline__ float band_dot(const float4* a, const float4* w, int 
 // window -- every lane keeps the last eight frames of its filter(s) and stores them as 32 contiguous bytes of the
 // (.., N, T) tensor (a 4-byte store per frame leaves partly written lines to be fetched again: MelSpectrogram / MFCC at
 // n_fft 2048, 0.90 -> 0.6 ms per 1024 clips).
+constexpr int kPhaseAhead = 9;   // passes whose phase inputs are requested with the row (the reference's 513-filter bank: 9)
+
 template <bool CPLX, int NSEG, bool EXACT, int CMW = 0>
 __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedParams p) {
   extern __shared__ float4 band_lds[];   // weight table, lane_start / lane_filter, one row per wave
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
       v[m] = src[k];
     }
   };
-  auto walk = [&](long long r, const In (&cur)[NSEG]) {
+  auto walk = [&](long long r, const In (&cur)[NSEG], auto phase_ahead) {   // phase_ahead: float[kPhaseAhead] or nullptr
     // prologue into the LDS row
 #pragma unroll
     for (int m = 0; m < NSEG; ++m) {
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       return;
     }
-    for (int q = 0; q < p.bank.n_passes; ++q) {
+    auto pass = [&](int q, float ph_ahead, bool have_phase) {
       const int f = lane_tab[(p.bank.n_passes + q) * 64 + lane];
       const float4* a = reinterpret_cast<const float4*>(absrow + lane_tab[q * 64 + lane]);
       float acc = 0.f;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
           if (p.offset) acc = AT_NORM(acc, off, sc, inv_sc);
         }
         if (p.phase_in) {
-          float ph = p.phase_in[r * p.ld_phase + f];
+          float ph = have_phase ? ph_ahead : p.phase_in[r * p.ld_phase + f];
           if (p.ph_offset) ph = __fadd_rn(__fmul_rn(ph, ph_sc), ph_off);
           float sn, cs;
           fast_sincosf(ph, sn, cs);
@@ -301,6 +303,13 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
           p.out[r * p.ld_out + f] = acc;
         }
       }
+    };
+    if constexpr (std::is_same<decltype(phase_ahead), std::nullptr_t>::value) {
+      for (int q = 0; q < p.bank.n_passes; ++q) pass(q, 0.f, false);
+    } else {
+#pragma unroll
+      for (int q = 0; q < kPhaseAhead; ++q)
+        if (q < p.bank.n_passes) pass(q, phase_ahead[q], true);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -313,9 +322,34 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
     // real rows (the inverse projection, |x| inputs): half the bytes per row and exp() per element -- the second
     // copy of the loop body costs more than the prefetch returns (A/B: 0.73 vs 0.70 ms); occupancy hides the load.
     // The longest complex rows (33 segments: 66 registers a copy) take the same single-buffered loop.
+    if constexpr (!CPLX && CMW == 0) {
+      // Polar.invert: the phases of a row are requested with the row, not one per pass behind the previous pass's
+      // store (loads and stores share vmcnt and return in order: every pass waited for a store's round trip)
+      if (p.phase_in && p.bank.n_passes <= kPhaseAhead) {
+        long long fcol[kPhaseAhead];
+#pragma unroll
+        for (int q = 0; q < kPhaseAhead; ++q) {
+          const int f = q < p.bank.n_passes ? lane_tab[(p.bank.n_passes + q) * 64 + lane] : 0;
+          fcol[q] = f > 0 ? f : 0;
+        }
+        auto fetch_phases = [&](long long row, float (&ph)[kPhaseAhead]) {
+          const float* prow = p.phase_in + row * p.ld_phase;
+#pragma unroll
+          for (int q = 0; q < kPhaseAhead; ++q) ph[q] = prow[fcol[q]];
+        };
+        // (one row ahead on two register sets, as the complex rows do it, measured slower here: 1.53 against 1.38 ms)
+        float pa[kPhaseAhead];
+        for (; r < r_end; ++r) {
+          fetch(r, ra);
+          fetch_phases(r, pa);
+          walk(r, ra, pa);
+        }
+        return;
+      }
+    }
     for (; r < r_end; ++r) {
       fetch(r, ra);
-      walk(r, ra);
+      walk(r, ra, nullptr);
     }
     return;
   } else {
@@ -323,10 +357,10 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
   fetch(r, ra);
   while (r < r_end) {
     fetch(r + 1 < r_end ? r + 1 : r, rb);
-    walk(r, ra);
+    walk(r, ra, nullptr);
     if (++r >= r_end) break;
     fetch(r + 1 < r_end ? r + 1 : r, ra);
-    walk(r, rb);
+    walk(r, rb, nullptr);
     ++r;
   }
   }

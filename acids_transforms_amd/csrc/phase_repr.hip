@@ -226,13 +226,19 @@ struct IntParams {
   const float* mag;      // optional (B, T, F) contiguous magnitudes
 };
 
-// the integrated phase of one bin goes out as it is, or as mag * exp(i phase) (PolarIF.invert in one pass)
+// the integrated phase of one bin goes out as it is, or as mag * exp(i phase) (PolarIF.invert in one pass).  The
+// magnitude is an argument: the callers request it with the rows of a batch -- loaded here, one per element, it queued
+// behind the previous element's store (loads and stores share vmcnt and return in order).
 template <bool POLAR>
-__device__ __forceinline__ void put_phase(const IntParams& p, long long idx, float ph) {
+__device__ __forceinline__ float mag_at(const IntParams& p, long long idx) {
+  if constexpr (POLAR) return p.mag[idx];
+  return 0.f;
+}
+template <bool POLAR>
+__device__ __forceinline__ void put_phase(const IntParams& p, long long idx, float ph, float m) {
   if constexpr (POLAR) {
     float sn, cs;
     fast_sincosf(ph, sn, cs);
-    const float m = p.mag[idx];
     reinterpret_cast<float2*>(p.out)[idx] = make_float2(m * cs, m * sn);
   } else {
     p.out[idx] = ph;
@@ -290,72 +296,87 @@ __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_integrate_kernel(In
     for (int k = 0; k < NC; ++k) acc[k] = 0.0;
     const float* src_row0 = p.y + b * T * ldy;
     const long long out_row0 = b * T * F;
-    auto step = [&](int k, long long s, float v) {   // s = position in scan order, row = FWD ? s : T-1-s
+    auto step = [&](int k, long long s, float v, float m) {   // s = position in scan order, row = FWD ? s : T-1-s
       const long long row = FWD ? s : T - 1 - s;
       v = prep(row, v);
       if (s >= 1) v = v * 2.0f;
       acc[k] += (double)v;
-      if (NC == 1 || on[k]) put_phase<POLAR>(p, out_row0 + row * F + fk[k], (float)acc[k]);
+      if (NC == 1 || on[k]) put_phase<POLAR>(p, out_row0 + row * F + fk[k], (float)acc[k], m);
     };
     long long s = 0;
     for (; s + kRowsAhead <= T; s += kRowsAhead) {
-      float v[NC][kRowsAhead];
+      float v[NC][kRowsAhead], m[NC][kRowsAhead];
 #pragma unroll
       for (int k = 0; k < NC; ++k)
 #pragma unroll
-        for (int r = 0; r < kRowsAhead; ++r) v[k][r] = src_row0[(FWD ? s + r : T - 1 - s - r) * ldy + fk[k]];
+        for (int r = 0; r < kRowsAhead; ++r) {
+          const long long row = FWD ? s + r : T - 1 - s - r;
+          v[k][r] = src_row0[row * ldy + fk[k]];
+          m[k][r] = mag_at<POLAR>(p, out_row0 + row * F + fk[k]);
+        }
 #pragma unroll
       for (int r = 0; r < kRowsAhead; ++r)
 #pragma unroll
-        for (int k = 0; k < NC; ++k) step(k, s + r, v[k][r]);
+        for (int k = 0; k < NC; ++k) step(k, s + r, v[k][r], m[k][r]);
       if (NC > 1) __syncthreads();     // lockstep: see phase_scan_kernel
     }
     for (; s < T; ++s)
 #pragma unroll
-      for (int k = 0; k < NC; ++k) step(k, s, src_row0[(FWD ? s : T - 1 - s) * ldy + fk[k]]);
+      for (int k = 0; k < NC; ++k) {
+        const long long row = FWD ? s : T - 1 - s;
+        step(k, s, src_row0[row * ldy + fk[k]], mag_at<POLAR>(p, out_row0 + row * F + fk[k]));
+      }
   } else {
     // fint_central (utils/misc.py:96-104), statement by statement.  Rows the reference never writes stay 0.
     auto z = [&](long long t) { return prep(t, src[t * ldy]); };
+    auto put = [&](long long row, float ph) { put_phase<POLAR>(p, base + row * F, ph, mag_at<POLAR>(p, base + row * F)); };
     if (T == 1) {
-      put_phase<POLAR>(p, base, z(0));
+      put(0, z(0));
       return;
     }
     float even = z(0);                       // out[0]
-    put_phase<POLAR>(p, base, even);
+    put(0, even);
     long long i = 2;
     for (; i + 2 * (kRowsAhead - 1) < T; i += 2 * kRowsAhead) {   // out[i] = out[i-2] + 4 x[i-1]
-      float v[kRowsAhead];
+      float v[kRowsAhead], m[kRowsAhead];
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(i + 2 * k - 1) * ldy];
+      for (int k = 0; k < kRowsAhead; ++k) {
+        v[k] = src[(i + 2 * k - 1) * ldy];
+        m[k] = mag_at<POLAR>(p, base + (i + 2 * k) * F);
+      }
 #pragma unroll
       for (int k = 0; k < kRowsAhead; ++k) {
         even = even + 4.0f * prep(i + 2 * k - 1, v[k]);
-        put_phase<POLAR>(p, base + (i + 2 * k) * F, even);
+        put_phase<POLAR>(p, base + (i + 2 * k) * F, even, m[k]);
       }
     }
     for (; i < T; i += 2) {
       even = even + 4.0f * z(i - 1);
-      put_phase<POLAR>(p, base + i * F, even);
+      put(i, even);
     }
-    for (long long j = 1; j < T; j += 2) put_phase<POLAR>(p, base + j * F, 0.0f);
+    for (long long j = 1; j < T; j += 2) put(j, 0.0f);
     // out[T-1]: x[T-1] when T is even (the forward chain only touched even rows), else the chain's last value
     float cur = ((T - 1) & 1) ? z(T - 1) : even;
-    put_phase<POLAR>(p, base + (T - 1) * F, cur);
+    put(T - 1, cur);
     i = T - 1;
     for (; i - 2 * (kRowsAhead - 1) >= 1; i -= 2 * kRowsAhead) {   // out[i-2] = out[i] - 4 x[i-1]; i = 1 writes row "-1"
-      float v[kRowsAhead];
+      float v[kRowsAhead], m[kRowsAhead];
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(i - 2 * k - 1) * ldy];
+      for (int k = 0; k < kRowsAhead; ++k) {
+        const long long ii = i - 2 * k;
+        v[k] = src[(ii - 1) * ldy];
+        m[k] = mag_at<POLAR>(p, base + ((ii - 2 >= 0) ? ii - 2 : T - 1) * F);
+      }
 #pragma unroll
       for (int k = 0; k < kRowsAhead; ++k) {
         const long long ii = i - 2 * k;
         cur = cur - 4.0f * prep(ii - 1, v[k]);
-        put_phase<POLAR>(p, base + ((ii - 2 >= 0) ? ii - 2 : T - 1) * F, cur);
+        put_phase<POLAR>(p, base + ((ii - 2 >= 0) ? ii - 2 : T - 1) * F, cur, m[k]);
       }
     }
     for (; i >= 1; i -= 2) {
       cur = cur - 4.0f * z(i - 1);
-      put_phase<POLAR>(p, base + ((i - 2 >= 0) ? i - 2 : T - 1) * F, cur);
+      put((i - 2 >= 0) ? i - 2 : T - 1, cur);
     }
   }
 }
