@@ -334,6 +334,41 @@ __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_integrate_kernel(In
       put(0, z(0));
       return;
     }
+    if ((T & 1) == 0) {
+      // Even T: the first loop writes the even rows, the second starts from x[T-1] and writes the odd ones (row "-1" =
+      // T-1 last): two independent chains, walked together -- twice the rows in flight, every row written once.
+      float even = z(0), cur = z(T - 1);
+      put(0, even);
+      const long long J = T / 2 - 1;          // paired steps; the second chain has one more (i = 1)
+      auto pair = [&](long long j, float ve, float vo, float me, float mo) {
+        const long long je = 2 * (j + 1), io = T - 1 - 2 * j;
+        even = even + 4.0f * prep(je - 1, ve);
+        put_phase<POLAR>(p, base + je * F, even, me);
+        cur = cur - 4.0f * prep(io - 1, vo);
+        put_phase<POLAR>(p, base + (io - 2) * F, cur, mo);
+      };
+      long long j = 0;
+      for (; j + kRowsAhead <= J; j += kRowsAhead) {
+        float ve[kRowsAhead], vo[kRowsAhead], me[kRowsAhead], mo[kRowsAhead];
+#pragma unroll
+        for (int k = 0; k < kRowsAhead; ++k) {
+          const long long je = 2 * (j + k + 1), io = T - 1 - 2 * (j + k);
+          ve[k] = src[(je - 1) * ldy];
+          vo[k] = src[(io - 1) * ldy];
+          me[k] = mag_at<POLAR>(p, base + je * F);
+          mo[k] = mag_at<POLAR>(p, base + (io - 2) * F);
+        }
+#pragma unroll
+        for (int k = 0; k < kRowsAhead; ++k) pair(j + k, ve[k], vo[k], me[k], mo[k]);
+      }
+      for (; j < J; ++j) {
+        const long long je = 2 * (j + 1), io = T - 1 - 2 * j;
+        pair(j, src[(je - 1) * ldy], src[(io - 1) * ldy], mag_at<POLAR>(p, base + je * F), mag_at<POLAR>(p, base + (io - 2) * F));
+      }
+      cur = cur - 4.0f * z(0);                // i = 1: out[-1]
+      put(T - 1, cur);
+      return;
+    }
     float even = z(0);                       // out[0]
     put(0, even);
     long long i = 2;

@@ -135,7 +135,7 @@ def test_real_imag_and_stacked_golden(golden, dev):
 def test_against_oracle_random_shapes(dev):
     """Ragged / tiny shapes and extra batch dims, complex input, all scan modes vs the oracle."""
     gen = torch.Generator().manual_seed(5)
-    for shape in [(1, 1, 1), (2, 2, 3), (3, 7, 65), (2, 3, 4, 33), (5, 513), (1, 64, 513)]:
+    for shape in [(1, 1, 1), (2, 2, 3), (3, 7, 65), (2, 3, 4, 33), (5, 513), (1, 64, 513), (3, 40, 65), (2, 690, 33), (2, 18, 7)]:
         X = (torch.randn(*shape, generator=gen) * torch.exp(2j * np.pi * torch.rand(*shape, generator=gen))).to(torch.complex64)
         Xd = X.to(dev)
         assert rel_max(cpu(ops.phase_scan(Xd, "angle")).numpy(), X.angle().numpy()) < TOL
@@ -290,7 +290,8 @@ def test_polar_one_pass_equals_parts(dev):
         p2(Xd)
 
 
-@pytest.mark.parametrize("shape", [(3, 2, 21, 513), (2, 1, 513), (1, 2, 129), (4, 33, 1025), (7, 257), (9, 67, 513), (70, 300)])
+@pytest.mark.parametrize("shape", [(3, 2, 21, 513), (2, 1, 513), (1, 2, 129), (4, 33, 1025), (7, 257), (9, 67, 513), (70, 300),
+                                   (3, 40, 513), (2, 690, 129)])
 def test_cartesian_and_polarif_work_inside_the_stacked_tensor(dev, shape):
     """Cartesian is one pack / unpack kernel, PolarIF's halves are written into / read from the stacked tensor in place
     (banded magnitude with a row stride, IF scan with a row stride, integration fused with mag * exp(i phase)): the
