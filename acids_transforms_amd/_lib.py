@@ -41,6 +41,8 @@ _SIGNATURES = {
     "at_phase_integrate": [c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f],
     "at_polar_to_complex": [c_f, c_f, c_i64, c_f, c_f],
     "at_phase_scan_strided": [c_f, c_f, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_i64, c_f],
+    "at_polarif_forward": [c_f, c_i64, c_i64, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_flt,
+                           c_f, c_f],
     "at_phase_integrate_polar": [c_f, c_i64, c_i64, c_i64, c_i64, c_int, c_f, c_f, c_f, c_f, c_f],
     "at_cartesian_pack": [c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f],
     "at_cartesian_unpack": [c_f, c_i64, c_int, c_f, c_f, c_f, c_f, c_f, c_f],

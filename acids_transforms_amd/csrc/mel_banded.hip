@@ -55,23 +55,6 @@ constexpr int kMaxRowK = 2112;      // longest input row: 33 segments of 64 (n_f
 constexpr int kMaxWalk = 512;       // longest band a lane walks
 constexpr size_t kLdsBudget = 160 * 1024;
 
-__device__ __forceinline__ float banded_contrast_fwd(float v, int mode, float eps) {
-  switch (mode) {
-    case C_LOG1P: return logf(1.0f + v);
-    case C_LOG: return logf(fmaxf(v, eps));
-    case C_LOG10: return log10f(fmaxf(v, eps));
-    default: return v;
-  }
-}
-__device__ __forceinline__ float banded_contrast_inv(float v, int mode, float eps) {
-  switch (mode) {
-    case C_LOG1P: return expf(v) - 1.0f;
-    case C_LOG: return expf(v) - eps;
-    case C_LOG10: return powf(10.0f, v);
-    default: return v;
-  }
-}
-
 // sum over one band: `quads` steps of four bins, values at a[j], this lane's weights at w[64 j].  The reads of four steps
 // are issued before the first multiply-add (one LDS round trip per four steps instead of one per step); the chain of
 // multiply-adds keeps the order of the plain loop, so the result does not change.

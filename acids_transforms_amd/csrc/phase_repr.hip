@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "../../include/acids_hip.h"
+#include "mel_gemm.h"   // C_* codes, banded_contrast_fwd
 #include "variants.h"
 
 namespace at_hip {
@@ -37,6 +38,20 @@ struct ScanParams {
   const float* scale;
   int bare;              // 1: plain fdiff_* of a real signal (no unwrap, no per-row division): utils/misc.py:65-81
   long long ld_out;      // floats between consecutive frames of `out` (F, or 2 F inside a stacked (.., T, 2, F) tensor)
+  // MAG (PolarIF.forward in one pass, clip-per-block layout only): the banded magnitude projection of the same rows,
+  // normalise(contrast(|X| @ bank)), rows of ld_out floats at mag_out.  The bank by filter: first bin, bins, offset of its
+  // weights in band_w (the dense bank's values from its first to its last non-zero row, ascending).
+  float* mag_out;
+  const int* band_start;
+  const int* band_len;
+  const int* band_off;
+  const float* band_w;
+  int n_w;               // floats in band_w
+  int row_floats;        // LDS row: F rounded up to a multiple of 4, + 4
+  int contrast;
+  float eps;
+  const float* mag_offset;
+  const float* mag_scale;
 };
 
 // the correction torch's unwrap adds for one frame-to-frame jump (utils/misc.py:19-24)
@@ -74,8 +89,9 @@ constexpr int kRowsAhead = 8;   // rows requested before the recurrence consumes
 // row, the end of row t meets the start of row t + 1 in the same block, and the barrier keeps both halves of every shared
 // segment within L2's reach.  Two columns per thread because 513 columns are 8.02 wavefronts: 257 threads = 5 wavefronts
 // per clip, 1024 clips resident at once.
-template <int MODE, bool CPLX, bool WIN, bool NORM, int NC>
+template <int MODE, bool CPLX, bool WIN, bool NORM, int NC, bool MAG = false>
 __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_scan_kernel(ScanParams p) {
+  static_assert(!MAG || (NC > 1 && CPLX && MODE != SCAN_ANGLE && MODE != SCAN_UNWRAP), "MAG: the IF scans of a complex spectrum, one block per clip");
   const long long T = p.T, F = p.F;
   long long b, fk[NC];
   bool on[NC];
@@ -158,6 +174,96 @@ __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_scan_kernel(ScanPar
     u_prev2[k] = u_prev[k];
     u_prev[k] = u;
   };
+  if constexpr (MAG) {
+    // PolarIF.forward: the rows this block has in registers for the scan also go, as |X|, through LDS into the banded
+    // projection -- thread j sums the bands of its NC filters over the batch's rows, in the order the banded walk of
+    // mel_banded.hip adds them (ascending bins, fmaf; the walk's zero-weight padding adds nothing), so the magnitude half
+    // equals at_mel_project_banded's bit for bit and the spectrum is read once instead of twice.
+    extern __shared__ float scan_lds[];
+    float* wl = scan_lds;                                   // the bank's weights
+    float* rows = scan_lds + ((p.n_w + 3) & ~3);           // kRowsAhead values of |X| per bin
+    for (int i = threadIdx.x; i < p.n_w; i += blockDim.x) wl[i] = p.band_w[i];
+    int fs[NC], fl[NC], fo[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      fs[k] = on[k] ? p.band_start[fk[k]] : 0;
+      fl[k] = on[k] ? p.band_len[fk[k]] : 0;
+      fo[k] = on[k] ? p.band_off[fk[k]] : 0;
+    }
+    float moff = 0.f, minv = 1.f;
+    if (p.mag_offset) {
+      moff = *p.mag_offset;
+      minv = 1.0f / *p.mag_scale;
+    }
+    float* mag_row0 = p.mag_out + b * T * p.ld_out;
+    // Where the 1.85 ms per 1024 x 690 x 513 go (builds with a part removed): the scan's own arithmetic (atan2, unwrap, the
+    // double accumulator, two IEEE divisions per bin) 0.8, the walk 0.35, contrast + normalise 0.2, the magnitude stores 0.1.
+    // (Requesting the next batch before working on this one costs 32 registers: 121, a fourth block no longer fits a CU
+    // and the 1024 clips take two rounds -- 1.85 -> 2.50 ms.)
+    for (long long t = 0; t < T; t += kRowsAhead) {
+      const int nr = (T - t < kRowsAhead) ? (int)(T - t) : kRowsAhead;
+      In v[NC][kRowsAhead];
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int r = 0; r < kRowsAhead; ++r) v[k][r] = src[(r < nr ? t + r : T - 1) * F + fk[k]];
+      // bin-major in LDS: the batch's eight |X| of a bin are 32 contiguous bytes (two 16-byte writes per column, two
+      // 16-byte reads per weight)
+      static_assert(kRowsAhead == 8, "two float4 per bin");
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (on[k]) {
+          float m[kRowsAhead];
+#pragma unroll
+          for (int r = 0; r < kRowsAhead; ++r) m[r] = __builtin_amdgcn_sqrtf(fmaf(v[k][r].x, v[k][r].x, v[k][r].y * v[k][r].y));
+          float4* dst = reinterpret_cast<float4*>(rows) + 2 * fk[k];
+          dst[0] = make_float4(m[0], m[1], m[2], m[3]);
+          dst[1] = make_float4(m[4], m[5], m[6], m[7]);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kRowsAhead; ++r)
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+          if (r < nr) step(k, t + r, v[k][r]);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        float acc[kRowsAhead];
+#pragma unroll
+        for (int r = 0; r < kRowsAhead; ++r) acc[r] = 0.f;
+        const float4* a = reinterpret_cast<const float4*>(rows) + 2 * fs[k];
+        const float* w = wl + fo[k];
+        auto mac = [&](float wj, const float4& lo, const float4& hi) {
+          acc[0] = fmaf(lo.x, wj, acc[0]);
+          acc[1] = fmaf(lo.y, wj, acc[1]);
+          acc[2] = fmaf(lo.z, wj, acc[2]);
+          acc[3] = fmaf(lo.w, wj, acc[3]);
+          acc[4] = fmaf(hi.x, wj, acc[4]);
+          acc[5] = fmaf(hi.y, wj, acc[5]);
+          acc[6] = fmaf(hi.z, wj, acc[6]);
+          acc[7] = fmaf(hi.w, wj, acc[7]);
+        };
+        int j = 0;
+        for (; j + 2 <= fl[k]; j += 2) {       // two weights a trip: their reads are in flight together
+          const float w0 = w[j], w1 = w[j + 1];
+          const float4 l0 = a[2 * j], h0 = a[2 * j + 1], l1 = a[2 * j + 2], h1 = a[2 * j + 3];
+          mac(w0, l0, h0);
+          mac(w1, l1, h1);
+        }
+        if (j < fl[k]) mac(w[j], a[2 * j], a[2 * j + 1]);
+        if (on[k]) {
+#pragma unroll
+          for (int r = 0; r < kRowsAhead; ++r)
+            if (r < nr) {
+              float m = banded_contrast_fwd(acc[r], p.contrast, p.eps);
+              if (p.mag_offset) m = (m - moff) * minv;
+              mag_row0[(t + r) * ldo + fk[k]] = m;
+            }
+        }
+      }
+      __syncthreads();       // lockstep (below), and the rows are free again
+    }
+  } else {
   long long t = 0;
   for (; t + kRowsAhead <= T; t += kRowsAhead) {
     In v[NC][kRowsAhead];
@@ -178,6 +284,7 @@ __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_scan_kernel(ScanPar
   for (; t < T; ++t)
 #pragma unroll
     for (int k = 0; k < NC; ++k) step(k, t, src[t * F + fk[k]]);
+  }
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     if (MODE == SCAN_IF_BACKWARD) emit(k, T - 1, (div && T > 1) ? u_prev[k] / (-kPi) : u_prev[k]);   // last row = the phase itself
@@ -497,6 +604,23 @@ static int phase_scan_impl(const float* X_complex, const float* phase, int64_t B
   return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
+// PolarIF.forward in one pass (clip-per-block layout only): IF scan + banded magnitude of the same rows
+template <int MODE, bool WIN, bool NORM>
+static void launch_scan_mag(int nc, size_t lds, hipStream_t s, const ScanParams& p) {
+  (void)nc;   // two columns per thread only: four need more registers than a 1024-thread block has (spills)
+  hipLaunchKernelGGL((phase_scan_kernel<MODE, true, WIN, NORM, 2, true>), dim3((unsigned)p.B), dim3(clip_block_threads(p.F, 2)), lds, s, p);
+}
+template <int MODE>
+static void launch_scan_mag1(bool win, bool norm, int nc, size_t lds, hipStream_t s, const ScanParams& p) {
+  if (win) {
+    if (norm) launch_scan_mag<MODE, true, true>(nc, lds, s, p);
+    else launch_scan_mag<MODE, true, false>(nc, lds, s, p);
+  } else {
+    if (norm) launch_scan_mag<MODE, false, true>(nc, lds, s, p);
+    else launch_scan_mag<MODE, false, false>(nc, lds, s, p);
+  }
+}
+
 template <bool POLAR>
 static int phase_integrate_impl(const float* y, int64_t ld_y, int64_t B, int64_t T, int64_t F, int method, int rescale,
                                 const float* offset, const float* scale, const float* mag, float* out, void* stream) {
@@ -548,6 +672,39 @@ int at_phase_scan_strided(const float* X_complex, const float* phase, int64_t B,
                           const float* frame_window, const float* offset, const float* scale, float* out, int64_t ld_out,
                           void* stream) {
   return phase_scan_impl(X_complex, phase, B, T, F, mode, bare, frame_window, offset, scale, out, ld_out, stream);
+}
+
+int at_polarif_forward(const float* X_complex, int64_t B, int64_t T, int64_t F, int method, const float* frame_window,
+                       const float* if_offset, const float* if_scale, const int* band_start, const int* band_len,
+                       const int* band_off, const float* band_w, int64_t n_w, int contrast, const float* mag_offset,
+                       const float* mag_scale, float eps, float* out_stacked, void* stream) {
+  if (B < 0 || T < 0 || F < 0 || n_w < 0) return AT_EINVAL;
+  if (B * T * F == 0) return AT_OK;
+  if (!X_complex || !out_stacked || !band_start || !band_len || !band_off || (n_w > 0 && !band_w)) return AT_EINVAL;
+  if ((if_offset == nullptr) != (if_scale == nullptr) || (mag_offset == nullptr) != (mag_scale == nullptr)) return AT_EINVAL;
+  if (method < SCAN_IF_FORWARD || method > SCAN_IF_CENTRAL || contrast < C_NONE || contrast > C_LOG10) return AT_EINVAL;
+  const int nc = clip_block_columns(F, B, 4);
+  const int row_floats = (int)((F + 3) & ~3ll) + 4;
+  const size_t lds = sizeof(float) * (size_t)(((n_w + 3) & ~3ll) + (long long)kRowsAhead * row_floats);
+  if (nc != 2 || lds > 64 * 1024) return AT_EUNSUPPORTED;      // the caller runs the two stand-alone kernels instead
+  ScanParams p = {(const float2*)X_complex, nullptr, out_stacked + F, B, T, F, frame_window, if_offset, if_scale, 0, 2 * F};
+  p.mag_out = out_stacked;
+  p.band_start = band_start;
+  p.band_len = band_len;
+  p.band_off = band_off;
+  p.band_w = band_w;
+  p.n_w = (int)n_w;
+  p.row_floats = row_floats;
+  p.contrast = contrast;
+  p.eps = eps;
+  p.mag_offset = mag_offset;
+  p.mag_scale = mag_scale;
+  hipStream_t s = (hipStream_t)stream;
+  const bool win = frame_window != nullptr, norm = if_offset != nullptr;
+  if (method == SCAN_IF_FORWARD) launch_scan_mag1<SCAN_IF_FORWARD>(win, norm, nc, lds, s, p);
+  else if (method == SCAN_IF_BACKWARD) launch_scan_mag1<SCAN_IF_BACKWARD>(win, norm, nc, lds, s, p);
+  else launch_scan_mag1<SCAN_IF_CENTRAL>(win, norm, nc, lds, s, p);
+  return hipGetLastError() == hipSuccess ? AT_OK : AT_ELAUNCH;
 }
 
 int at_phase_integrate(const float* y, int64_t B, int64_t T, int64_t F, int method, int rescale, const float* offset,

@@ -637,10 +637,19 @@ def polarif_forward(x, band, contrast, mag_offset, mag_scale, eps, method, frame
     B, T, F = _btf(x)
     assert band.N == F and band.K == F and band.eligible and method in ("forward", "backward", "central")
     out = torch.empty(x.shape[:-1] + (2, F), dtype=torch.float32, device=x.device)
-    _project_banded(x, 0, band, contrast, False, mag_offset, mag_scale, eps, out, F, 0, ld_out=2 * F)
     if frame_window is not None:
         frame_window = _f32c(frame_window.to(x.device))
         assert frame_window.numel() == T
+    # one pass over the spectrum where the clip-per-block scan applies (>= 64 clips, 256..4096 bins; the library answers
+    # AT_EUNSUPPORTED otherwise, and under variant("scan_layout", 1)); same bits as the two kernels below
+    start, length, woff, w = band.by_filter(x.device)
+    err = lib().at_polarif_forward(ptr(x), B, T, F, SCAN_MODES[method], ptr(frame_window), ptr(if_offset), ptr(if_scale),
+                                   ptr(start), ptr(length), ptr(woff), ptr(w), w.numel(), contrast_code(contrast),
+                                   ptr(mag_offset), ptr(mag_scale), float(eps), ptr(out), stream_ptr())
+    if err != -2:            # AT_EUNSUPPORTED
+        check(err, "at_polarif_forward")
+        return out
+    _project_banded(x, 0, band, contrast, False, mag_offset, mag_scale, eps, out, F, 0, ld_out=2 * F)
     check(lib().at_phase_scan_strided(ptr(x), None, B, T, F, SCAN_MODES[method], 0, ptr(frame_window), ptr(if_offset),
                                       ptr(if_scale), ctypes.c_void_p(out.data_ptr() + 4 * F), 2 * F, stream_ptr()),
           "at_phase_scan_strided")

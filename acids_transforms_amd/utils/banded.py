@@ -184,6 +184,12 @@ class BandedBank:
                             and 8 * (4 * 568 + 22 * 64 + 1024) + 4 * (4 * row2k + weights.size) + 8 * 64 * self.n_passes
                             <= 80 * 1024)          # (the window joins them in LDS when another 8 KB fit: launcher)
         self.pass_len = pass_len                              # host array handed to the C ABI
+        # the same bank by filter, for the one-pass PolarIF.forward (at_polarif_forward): first bin, bins up to the last
+        # non-zero weight, offset of that run in one flat weight array
+        length = np.where(has, last - first + 1, 0).astype(np.int32)
+        offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int32)
+        flat = np.concatenate([b[first[f]:first[f] + length[f], f] for f in range(N)] or [np.zeros(0, np.float32)])
+        self._by_filter_host = (first.astype(np.int32), length, offset, flat.astype(np.float32))
         self.walked_macs = 64 * int(pass_len.sum())           # multiply-adds issued per frame (incl. zeros)
         self._host = (lane_filter, lane_start, weights)
         self._dev = {}
@@ -198,6 +204,13 @@ class BandedBank:
             cycles += c
             ideal += i
         return cycles, ideal
+
+    def by_filter(self, device):
+        """(band_start, band_len, band_off, band_w) tensors on `device` (eligible banks only)."""
+        key = "by_filter:" + str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in self._by_filter_host)
+        return self._dev[key]
 
     def on(self, device):
         """(lane_filter, lane_start, weights) tensors on `device`."""

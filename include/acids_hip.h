@@ -345,6 +345,19 @@ int at_phase_integrate(const float *y, int64_t B, int64_t T, int64_t F, int meth
 int at_phase_scan_strided(const float *X_complex, const float *phase, int64_t B, int64_t T, int64_t F, int mode, int bare,
                           const float *frame_window, const float *offset, const float *scale, float *out, int64_t ld_out,
                           void *stream);
+/* PolarIF.forward in one pass (spectral_repr.py:505-537 = Magnitude.forward :186-200, :222-227 next to IF.forward :318-335,
+ * :350-358, stacked on dim -2): X (B, T, F) complex64 -> out_stacked (B, T, 2, F) with [.., 0, :] =
+ * normalise(contrast(|X| @ bank)) and [.., 1, :] = normalise(IF(X)) (`method`, frame_window, if_offset / if_scale as in
+ * at_phase_scan).  The bank is given by filter (device arrays): band_start[f] first bin with a non-zero weight,
+ * band_len[f] bins up to the last one (0: empty filter), band_off[f] offset of those weights in band_w (n_w floats;
+ * start + len <= F, off + len <= n_w are the caller's to guarantee).  Both halves equal at_mel_project_banded's and
+ * at_phase_scan_strided's bit for bit; the spectrum is read once.  One block per clip: AT_EUNSUPPORTED unless B >= 64,
+ * 256 <= F <= 4096, rows that are not whole 64-byte segments and a bank whose weights fit LDS beside eight rows --
+ * the caller then runs those two entry points. */
+int at_polarif_forward(const float *X_complex, int64_t B, int64_t T, int64_t F, int method, const float *frame_window,
+                       const float *if_offset, const float *if_scale, const int *band_start, const int *band_len,
+                       const int *band_off, const float *band_w, int64_t n_w, int contrast, const float *mag_offset,
+                       const float *mag_scale, float eps, float *out_stacked, void *stream);
 /* IF.invert fused with SpectralRepresentation.invert's mag * exp(i * phase) (spectral_repr.py:360-373, 449-451): y has
  * frames ld_y >= F floats apart (the phase half of a stacked tensor: y = stacked + F, ld_y = 2 F), mag is (B, T, F)
  * contiguous, out_complex (B, T, F) complex64. */

@@ -332,6 +332,43 @@ def test_cartesian_and_polarif_work_inside_the_stacked_tensor(dev, shape):
     assert p2._in_place_parts(F, False) is None
 
 
+@pytest.mark.parametrize("shape", [(64, 19, 513), (70, 8, 257), (65, 1, 513), (64, 17, 1025), (66, 23, 300), (64, 3, 2049)])
+def test_polarif_forward_one_pass_equals_the_two_kernels(dev, shape):
+    """>= 64 clips of 256..4096 bins: PolarIF.forward is ONE kernel (at_polarif_forward: the clip-per-block IF scan with
+    the banded magnitude of the same rows summed from LDS).  Both halves bit-identical to the stand-alone kernels
+    (`variant("scan_layout", 1)` sends the call down the two-kernel path), every method, weighted or not, every
+    contrast, with and without normalisation; the tail batch (T not a multiple of 8) and single-frame clips included."""
+    from acids_transforms_amd._lib import variant
+    gen = torch.Generator().manual_seed(sum(shape) + 1)
+    X = (torch.randn(*shape, generator=gen) * torch.exp(2j * np.pi * torch.rand(*shape, generator=gen))).to(torch.complex64)
+    Xd = X.to(dev)
+    F = shape[-1]
+    cases = [("forward", False, "log1p", "bipolar"), ("backward", True, "log", "unipolar"), ("central", False, "log10", None),
+             ("forward", True, None, "gaussian"), ("central", True, "log1p", "unipolar")]
+    for method, weighted, contrast, mode in cases:
+        if shape[-2] == 1 and (method == "central" or weighted):
+            continue
+        p = A.PolarIF(magnitude_args={"mode": mode, "n_fft": 2 * (F - 1), "contrast": contrast},
+                      phase_args={"mode": "gaussian" if mode else None, "method": method, "weighted": weighted}).to(dev)
+        p.scale_data(Xd[:8])
+        assert p._in_place_parts(F, False) is not None
+        y = p(Xd)
+        with variant("scan_layout", 1):
+            want = p(Xd)
+        assert y.shape == shape[:-1] + (2, F)
+        assert torch.equal(y[..., 1, :], want[..., 1, :]), (method, weighted, contrast, mode, "IF half")
+        assert torch.equal(y[..., 0, :], want[..., 0, :]), (method, weighted, contrast, mode, "magnitude half")
+        assert torch.equal(y[..., 0, :], p.magnitude(Xd)) and torch.equal(y[..., 1, :], p.phase(Xd))
+    # the raw entry point refuses what the layout does not cover
+    from acids_transforms_amd._lib import lib, ptr
+    small = Xd[:8].contiguous()
+    st, ln, wo, w = p._in_place_parts(F, False).by_filter(dev)
+    out = torch.empty(small.shape[:-1] + (2, F), device=dev)
+    rc = lib().at_polarif_forward(ptr(small), 8, shape[-2], F, 1, None, None, None, ptr(st), ptr(ln), ptr(wo), ptr(w),
+                                  w.numel(), 1, None, None, 1e-7, ptr(out), None)
+    assert rc == -2
+
+
 def test_compose_stft_polar_is_one_kernel(dev):
     """ComposeAudioTransform(STFT|DGT + Polar) with default parts: framing, FFT, banded magnitude and phase in a
     single kernel that never writes the complex spectrum.  Same values as stage by stage; the STFT stage's
