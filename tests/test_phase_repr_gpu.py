@@ -367,6 +367,11 @@ def test_polarif_forward_one_pass_equals_the_two_kernels(dev, shape):
     rc = lib().at_polarif_forward(ptr(small), 8, shape[-2], F, 1, None, None, None, ptr(st), ptr(ln), ptr(wo), ptr(w),
                                   w.numel(), 1, None, None, 1e-7, ptr(out), None)
     assert rc == -2
+    # ... and takes what it does (so the comparisons above were between two different routes)
+    out = torch.empty(shape[:-1] + (2, F), device=dev)
+    rc = lib().at_polarif_forward(ptr(Xd), shape[0], shape[-2], F, 1, None, None, None, ptr(st), ptr(ln), ptr(wo), ptr(w),
+                                  w.numel(), 1, None, None, 1e-7, ptr(out), None)
+    assert rc == (0 if F <= 1025 else -2), (F, rc)
 
 
 def test_compose_stft_polar_is_one_kernel(dev):
