@@ -91,10 +91,13 @@ __device__ __forceinline__ float band_dot(const float4* a, const float4* w, int 
 // window -- every lane keeps the last eight frames of its filter(s) and stores them as 32 contiguous bytes of the
 // (.., N, T) tensor (a 4-byte store per frame leaves partly written lines to be fetched again: MelSpectrogram / MFCC at
 // n_fft 2048, 0.90 -> 0.6 ms per 1024 clips).
-constexpr int kPhaseAhead = 9;   // passes whose phase inputs are requested with the row (the reference's 513-filter bank: 9)
 
 template <bool CPLX, int NSEG, bool EXACT, int CMW = 0>
 __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedParams p) {
+  // passes whose phase inputs are requested with the row (Polar.invert): a bank of K filters over K bins has as many passes
+  // as the row has segments -- 9 at n_fft 1024, 17 at 2048; the 33 of n_fft 4096 keep the load inside the pass (requested
+  // ahead they change nothing there: 2.73 ms either way)
+  constexpr int kPhaseAhead = NSEG <= 17 ? NSEG : 1;
   extern __shared__ float4 band_lds[];   // weight table, lane_start / lane_filter, one row per wave
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bookkeeping on the scalar unit
@@ -309,7 +312,8 @@ __global__ __launch_bounds__(64 * kBandedWaves) void mel_banded_kernel(BandedPar
       // Polar.invert: the phases of a row are requested with the row, not one per pass behind the previous pass's
       // store (loads and stores share vmcnt and return in order: every pass waited for a store's round trip)
       if (p.phase_in && p.bank.n_passes <= kPhaseAhead) {
-        long long fcol[kPhaseAhead];
+        // the column of every pass in registers (read back from the LDS table at every row instead: 1.42 -> 1.66 ms)
+        int fcol[kPhaseAhead];
 #pragma unroll
         for (int q = 0; q < kPhaseAhead; ++q) {
           const int f = q < p.bank.n_passes ? lane_tab[(p.bank.n_passes + q) * 64 + lane] : 0;
