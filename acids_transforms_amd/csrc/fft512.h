@@ -22,6 +22,18 @@
 
 namespace at_hip {
 
+// s_setprio of the forward kernels' phases (stft1024.hip: transform > stores > epilogue); -DAT_WAVE_PRIORITY=0 builds
+// without it for A/B runs
+#ifndef AT_WAVE_PRIORITY
+#define AT_WAVE_PRIORITY 1
+#endif
+template <int LEVEL>
+__device__ __forceinline__ void wave_priority() {
+#if AT_WAVE_PRIORITY
+  __builtin_amdgcn_s_setprio(LEVEL);
+#endif
+}
+
 constexpr int kFftLdsFloat2PerWave = 568;  // 7*72 + 63 + 1
 
 // twiddle table layout (float2 each), built on the host in double precision:

@@ -413,6 +413,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
       p.phase[(nyq_dst - p.out)] = fast_atan2f(nyq_pending.y, nyq_pending.x);
   };
   auto frame_body = [&](const float2 (&fresh)[HS]) {
+    // Wave priority.  Four waves share a SIMD, each somewhere else in its frame: the transform is one long chain of
+    // dependent packed arithmetic between LDS exchanges, the stores and the epilogue are short bursts between waits.
+    // Left to the default arbitration a wave in its epilogue takes issue slots from a wave in its transform, and every
+    // frame's stores leave later than they could.  Transform 3 > stores 1 > epilogue 0 (same-box A/B of six shapes,
+    // profiles/r04y_wave_priority.md): fused forward -1.6 % on a box whose memory is slow with mixed traffic, -4 % on
+    // the others; features only -5.5 %; plain -2 %.  The inverse has no such phases (two shapes tried: 0 / +3 %).
+    wave_priority<3>();
     float2 v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -450,6 +457,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = to_f2(z[m]);
       if constexpr (AL) {
+        wave_priority<1>();
         const bool lo = lane < rot;
         const v2f s0 = lo ? carry : z[0];
         if (head) {
@@ -529,6 +537,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
         }
       }
     };
+    wave_priority<0>();
     if constexpr (MEL != 0 && FQ0 > 0) {
       static_assert(SP == 2 && (CMBUF == 0 || CMBUF == 2) && !POLAR, "fixed-length epilogue: two passes, no phase rows");
       float* absrow = reinterpret_cast<float*>(lds);

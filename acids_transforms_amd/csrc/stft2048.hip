@@ -259,6 +259,7 @@ __global__ __launch_bounds__(64 * W2KR, 4) void stft2048_run_fwd_kernel(P2kRun p
   auto put = [&](float2* dst, v2f val) { __builtin_nontemporal_store(val, reinterpret_cast<v2f*>(dst)); };
 
   auto frame_body = [&](const float4 (&fresh)[2]) {
+    wave_priority<3>();        // transform > stores, as in stft1024.hip
     v2f ze[8], zo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(64 * W2KR, 4) void stft2048_run_fwd_kernel(P2kRun p
       const v2f d = sub_conj(z[m], pm[m]);
       z[m] = add_mi(e, cmul_v(d, lds_read_single(w2 + 64 * m)));
     }
+    wave_priority<1>();
     const bool lo = lane < rot;
     const v2f s0 = lo ? carry : z[0];
     if (head) {
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(64 * W2KR, 4) void stft2048_run_fwd_kernel(P2kRun p
       sp += 1024;
       ++rot;
     }
+    wave_priority<0>();
   };
 
   long long t = t0;
@@ -676,6 +679,7 @@ __global__ __launch_bounds__(64 * W2K, 2) void stft2048_mel_kernel(P2kMel p) {
   float4 nxt[8];
   load_frame2k(lp, f_begin, lane, nxt);
   for (long long f = f_begin; f < f_end; ++f) {
+    wave_priority<3>();        // transform > epilogue
     v2f ze[8], zo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -707,6 +711,7 @@ __global__ __launch_bounds__(64 * W2K, 2) void stft2048_mel_kernel(P2kMel p) {
     }
     if (lane == 0) absrow[1024] = p.power2 ? nyq * nyq : fabsf(nyq);
     wave_lds_sync();
+    wave_priority<0>();
 
     const long long b = cb, t = ct;
     if (++ct == p.T) {

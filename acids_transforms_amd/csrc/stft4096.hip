@@ -287,6 +287,7 @@ __global__ __launch_bounds__(64 * W4K, 2) void stft4096_run_fwd_kernel(P4kRun p)
   auto put = [&](float2* dst, v2f val) { __builtin_nontemporal_store(val, reinterpret_cast<v2f*>(dst)); };
 
   auto frame_body = [&](const float4 (&fa)[2], const float4 (&fb)[2]) {
+    wave_priority<3>();        // transform > stores, as in stft1024.hip
     v2f z0[8], z1[8], z2[8], z3[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(64 * W4K, 2) void stft4096_run_fwd_kernel(P4kRun p)
       const v2f d = sub_conj(z[m], pm[m]);
       z[m] = scale_add_mi(e, hh, cmul_v(d, wh[64 * m]));
     }
+    wave_priority<1>();
     const bool lo = lane < rot;
     const v2f s0 = lo ? carry : z[0];
     if (head) {
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(64 * W4K, 2) void stft4096_run_fwd_kernel(P4kRun p)
       sp += 2048;
       ++rot;
     }
+    wave_priority<0>();
   };
 
   long long t = t0;

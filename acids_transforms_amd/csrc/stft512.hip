@@ -290,6 +290,7 @@ __global__ __launch_bounds__(64 * W5R, 4) void stft512_run_fwd_kernel(P5Run p) {
   };
 
   auto pair_body = [&](const float2 (&fresh)[4], bool has_b) {
+    wave_priority<3>();        // transform > stores, as in stft1024.hip
     v2f y[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = (v2f){raw[j].x * win[j].x, raw[j].y * win[j].y};
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(64 * W5R, 4) void stft512_run_fwd_kernel(P5Run p) {
     }
     const v2f na = {2.0f * (ha[0].x - ha[0].y), 0.0f};     // X_A[256], on the lane whose column is 0 (= lane rot)
     const float nbx = 2.0f * (hb[0].x - hb[0].y);
+    wave_priority<1>();
     emit_frame(xa, na);
     if (has_b) {
       // the second frame one lane up: its columns then sit where a frame with rotation rot + 1 wants them
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(64 * W5R, 4) void stft512_run_fwd_kernel(P5Run p) {
       const v2f nb = {__shfl(nbx, src, 64), 0.0f};
       emit_frame(xs, nb);
     }
+    wave_priority<0>();
   };
 
   long long i = i0;
