@@ -795,6 +795,7 @@ __global__ __launch_bounds__(64 * W5) void stft512_mel_kernel(P5Mel p) {
   float2 nxt[8];
   load_half_frame5(lp, 2 * pr_begin + (lane & 1), lane, nxt);
   for (long long pr = pr_begin; pr < pr_end; ++pr) {
+    wave_priority<3>();        // transform > epilogue, as in stft1024.hip
     v2f y[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = (v2f){nxt[j].x * win[j].x, nxt[j].y * win[j].y};
@@ -825,6 +826,7 @@ __global__ __launch_bounds__(64 * W5) void stft512_mel_kernel(P5Mel p) {
       rowb[256] = p.power2 ? nb * nb : fabsf(nb);
     }
     wave_lds_sync();
+    wave_priority<0>();
     // one walk for both frames: every weight quad is read once
     const float4* w = reinterpret_cast<const float4*>(wlds) + lane;
     constexpr int NQ = CMW > 0 ? CMW : 16;
