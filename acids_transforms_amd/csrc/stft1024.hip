@@ -1342,6 +1342,12 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   const long long slots = resident_waves(kernel, 64 * NW, dyn_lds);
   const long long fpr = plan_units_per_run(B, T, slots, 8, hop == 128 ? 5 : 1);
   p.frames_per_run = fpr;
+  // The plain forward (no epilogue) with work for every slot several times over: 16-frame runs.  One workgroup's eight
+  // runs are then a 128-frame tile of the output stream and the hardware dispatches the tiles in address order -- the
+  // compact, advancing write front of profiles/r04_launch_shape.md: 0.75 -> 0.72 ms per 1024 clips, measured again under
+  // the wave priorities (same-box, r04y).  The fused kernels lose at every run length below the planner's (their run
+  // start costs 2.4-3.4 us of wave time) and keep one long run per wave.
+  if (!bank && hop == 256 && fpr > 16 && B * ((T + 15) / 16) >= 2 * slots) p.frames_per_run = 16;
   if (const char* e = dev_env("ACIDS_FWD_FPR")) {     // dev builds: run length A/B, clamped to what the kernels assume
     const long long v = atoll(e);
     if (v >= 8 && v <= T) p.frames_per_run = v;
