@@ -52,4 +52,14 @@ inline long long plan_units_per_run(long long B, long long units, long long slot
   return best_upr;
 }
 
+// The plain forwards (no epilogue) with work for every slot at least twice over take SHORT runs instead of the planner's
+// one long run per wave: a workgroup's runs are then one tile of the output stream and the hardware dispatches the tiles
+// in address order -- the compact, advancing write front of profiles/r04_launch_shape.md (n_fft 1024: 0.730 -> 0.699 ms).
+// Only there: at n_fft 2048 / 4096 (8-frame runs) the same cut is 5-10 % SLOWER (a run start re-reads 3/4 of a longer
+// window), at 512 it is lost in the noise.
+inline long long short_runs_if_full(long long B, long long units, long long slots, long long planned, long long target) {
+  if (planned > target && B * ((units + target - 1) / target) >= 2 * slots) return target;
+  return planned;
+}
+
 }  // namespace at_hip

@@ -1347,7 +1347,7 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
   // compact, advancing write front of profiles/r04_launch_shape.md: 0.75 -> 0.72 ms per 1024 clips, measured again under
   // the wave priorities (same-box, r04y).  The fused kernels lose at every run length below the planner's (their run
   // start costs 2.4-3.4 us of wave time) and keep one long run per wave.
-  if (!bank && hop == 256 && fpr > 16 && B * ((T + 15) / 16) >= 2 * slots) p.frames_per_run = 16;
+  if (!bank && hop == 256) p.frames_per_run = short_runs_if_full(B, T, slots, fpr, 16);
   if (const char* e = dev_env("ACIDS_FWD_FPR")) {     // dev builds: run length A/B, clamped to what the kernels assume
     const long long v = atoll(e);
     if (v >= 8 && v <= T) p.frames_per_run = v;
