@@ -125,7 +125,7 @@ def lib():
 
 
 # kernel variants (include/acids_hip.h AT_VARIANT_*): same results, different kernels; for tests and A/B runs
-VARIANTS = {"epilogue": 0, "frame_kernels": 1, "small_projection": 2, "scan_layout": 3, "pghi_kernel": 4}
+VARIANTS = {"epilogue": 0, "frame_kernels": 1, "small_projection": 2, "scan_layout": 3, "pghi_kernel": 4, "istft_runs": 5}
 
 
 class variant:

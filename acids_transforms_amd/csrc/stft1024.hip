@@ -937,6 +937,22 @@ __device__ __forceinline__ float2 scaled_window(const float* window, int i) {
   return make_float2(w.x * (1.0f / 1024.0f), w.y * (1.0f / 1024.0f));
 }
 
+// one frame: spectrum -> time samples z[m] = (x[2n], x[2n+1]), n = lane + 64 m, BEFORE the synthesis window.  The
+// overlap-add kernels take the window inside their accumulation, acc = fma(z, w, acc), spelled out: left to the
+// compiler's contraction the same sum came out as fma in one kernel and as round(z w) + acc in another (whose pieces
+// travel through LDS), and a clip's bits must not depend on which kernel its batch size selects.
+template <typename TW>
+__device__ __forceinline__ void synth_frame_nowin(const float2 (&v)[8], float nyq_re, const TW& tw, float2* lds, int lane,
+                                                  v2f (&z)[8]) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) z[m] = to_v(v[m]);
+  irfft_split(z, tw, lane, nyq_re);
+  fft512<true>(z, tw, lds, lane);
+}
+__device__ __forceinline__ v2f ola_window(const float2* win, int lane, int m) {
+  return lds_read_single(reinterpret_cast<const v2f*>(win) + lane + 64 * m);   // window / 1024, workgroup-shared LDS copy
+}
+
 // one frame: spectrum -> windowed time samples y[m] = (x[2n], x[2n+1]) * w, n = lane + 64 m
 template <typename TW>
 __device__ __forceinline__ void synth_frame(float2 (&v)[8], float nyq_re, const TW& tw, const float2* win,
@@ -993,14 +1009,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS
   Twiddles tw_regs;
   if (!TWLDS) load_twiddles<true>(tw_regs, p.tw, lane);
   const LdsTwiddles<true> tw_lds = {twtab, lane};
-  auto synth = [&](float2 (&v)[8], float nyq) {
-    if (TWLDS) synth_frame(v, nyq, tw_lds, win, lds, lane);
-    else synth_frame(v, nyq, tw_regs, win, lds, lane);
+  auto synth = [&](const float2 (&v)[8], float nyq, v2f (&z)[8]) {
+    if (TWLDS) synth_frame_nowin(v, nyq, tw_lds, lds, lane, z);
+    else synth_frame_nowin(v, nyq, tw_regs, lds, lane, z);
   };
 
-  float2 acc[8];
+  v2f acc[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
+  for (int m = 0; m < 8; ++m) acc[m] = (v2f){0.f, 0.f};
 
   const long long fbase = b * p.T;
   float* yclip = p.y + b * (H * nslots);
@@ -1018,9 +1034,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS
     float nyq;
     if constexpr (IN_MODE == IN_GL) raw_to_spectrum(q, v, nyq, p.gl_mom);
     else raw_to_spectrum(q, v, nyq);
-    synth(v, nyq);
+    v2f z[8];
+    synth(v, nyq, z);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) acc[m] = cadd(acc[m], v[m]);
+    for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(z[m], ola_window(win, lane, m), acc[m]);
   };
   // finished hops leave through non-temporal stores: written once, read by nobody here (the pattern-only copy kernel
   // of tools/ubench/stream_pattern2.hip gains 3-4 % from them: 0.717 -> 0.689 ms)
@@ -1031,6 +1048,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS
     *dst = val;
 #endif
   };
+  static_assert(sizeof(v2f) == sizeof(float2), "");
   auto emit = [&](long long j, const float2* env) {
     float2* dst = reinterpret_cast<float2*>(yclip + j * H);
 #pragma unroll
@@ -1051,7 +1069,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS
 #pragma unroll
     for (int m = 0; m < 8 - HS; ++m) acc[m] = acc[m + HS];
 #pragma unroll
-    for (int m = 8 - HS; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
+    for (int m = 8 - HS; m < 8; ++m) acc[m] = (v2f){0.f, 0.f};
   };
   // reciprocal of the full-overlap envelope, shared by the steady-state loop and the edge steps: a hop's value
   // must not depend on which of the two emitted it, i.e. on how the launch cut the clip into runs
@@ -1122,6 +1140,197 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_MODE == IN_GL ? 2 : (TWLDS
   while (t <= t_last) generic_step();
 }
 
+// K3 for full batches (round 5): the same transform, the same additions in the same order, cut for the memory system.
+// The kernel above gives each wave ONE long run of a clip (173 hops at 1024 clips) and pays three warm-up frames per run;
+// the chip then reads 2048 fronts a run length apart.  The inverse's access pattern runs 6-8 % faster when the
+// workgroups of a launch walk the streams in address order (tools/ubench/stream_pattern3.hip, "inv D": 0.61 against
+// 0.65 ms), but at 16-frame runs the three warm-up frames would be 19 % more transforms.  Here a WORKGROUP owns a tile of
+// consecutive frames of one clip and the overlap state crosses the cuts between its waves through LDS instead of being
+// recomputed:
+//   * wave w transforms ONLY its own frames [ta, tb) and emits the hops [ta + 3, tb + 3) (hop p = frames p-3 .. p);
+//   * the first three frames of a wave also feed the last three hops of the wave before it: their hop-sized pieces
+//     (3 + 2 + 1 = six 1-KB pieces) are parked in LDS UNSUMMED;
+//   * after ONE workgroup barrier wave w adds the pieces of wave w + 1 to its three open hops one frame at a time -- the
+//     additions happen in frame order, ((F[p-3] + F[p-2]) + F[p-1]) + F[p] exactly as in the long-run kernel, so the bits do
+//     not depend on where the cuts are (or on which of the two kernels ran);
+//   * the tile's last wave has no successor in the workgroup and transforms the next tile's first three frames itself
+//     (3 extra transforms per tile: 2.4 % at 125-frame tiles; it is given three frames fewer so that the waves finish together).
+// No wave ever waits for another wave's transforms: by the time a wave has finished its own frames its successor parked
+// its pieces long ago.  Tiles are dispatched in address order (tile = blockIdx.x).
+template <int IN_MODE, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void istft1024_tile_kernel(InvParams p) {
+  constexpr int HS = 2, R = 4, H = 256;
+  constexpr int kFull = (1 << R) - 1;
+  static_assert(IN_MODE != IN_GL, "the Griffin-Lim form keeps the long-run kernel");
+  __shared__ float2 lds_all[NW * kFftLdsFloat2PerWave + 512];
+  __shared__ float4 park_all[NW * 6 * 64];          // wave w: six hop-sized pieces of its first three frames
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float2* lds = lds_all + wave * kFftLdsFloat2PerWave;
+  float2* win = lds_all + NW * kFftLdsFloat2PerWave;
+
+  // the tile and this wave's share of it (everything wave-uniform)
+  const long long tile = blockIdx.x;
+  const long long b = tile / p.runs_per_clip;             // runs_per_clip: tiles per clip
+  const long long k = tile - b * p.runs_per_clip;
+  const long long n = p.slots_per_run;                     // frames per wave (the last wave of a full tile: n - 3)
+  const long long T = p.T;
+  const long long tile0 = k * p.frames_per_block;          // frames_per_block: frames per tile = (NW - 1) n + n - 3
+  long long tile1 = tile0 + p.frames_per_block;
+  if (tile1 > T) tile1 = T;
+  auto share = [&](int w, long long& a, long long& e) {
+    a = tile0 + w * n;
+    if (a > tile1) a = tile1;
+    e = (w == NW - 1) ? tile1 : a + n;
+    if (e > tile1) e = tile1;
+  };
+  long long ta, tb;
+  share(wave, ta, tb);
+  bool self_cool = true;                                    // this wave closes its last three hops itself
+  if (wave < NW - 1) {
+    long long a2, e2;
+    share(wave + 1, a2, e2);
+    self_cool = e2 - a2 < 3;
+  }
+  long long t_stop = (self_cool && tb > ta) ? tb + 3 : tb;  // frames this wave transforms: [ta, t_stop)
+  if (t_stop > T) t_stop = T;
+  const bool parks = wave > 0 && ta > 0;                    // somebody in this workgroup may read the pieces
+  const long long pe0 = ta == 0 ? 2 : ta + 3;               // first padded hop this wave emits (hops 0, 1 are trimmed)
+  const long long pe1 = tb + 3;                             // one past the last (hop T is the clip's last)
+
+  const long long fbase = b * T;
+  float* yclip = p.y + b * (H * (T - 1));
+  long long t = ta;
+  RawFrame<IN_MODE> q0 = {}, q1 = {};                       // frames t and t + 1, requested before the tables are staged
+  if (t < t_stop) load_raw(p, fbase + t, lane, q0);
+  if (t + 1 < t_stop) load_raw(p, fbase + t + 1, lane, q1);
+
+  for (int i = threadIdx.x; i < 512; i += 64 * NW) win[i] = scaled_window(p.window, i);
+  Twiddles tw;
+  load_twiddles<true>(tw, p.tw, lane);
+  __syncthreads();
+
+  v2f acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = (v2f){0.f, 0.f};
+  // z: the frame's samples before the window (what is parked); the window enters in the accumulation, one fma per sample
+  auto consume = [&](const RawFrame<IN_MODE>& q, v2f (&z)[8]) {
+    float2 v[8];
+    float nyq;
+    raw_to_spectrum(q, v, nyq);
+    synth_frame_nowin(v, nyq, tw, lds, lane, z);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(z[m], ola_window(win, lane, m), acc[m]);
+  };
+  auto put_y = [&](float2* dst, float2 val) {
+    __builtin_nontemporal_store((v2f){val.x, val.y}, reinterpret_cast<v2f*>(dst));
+  };
+  float2 rcp[HS];
+  {
+    const float2* env_full = reinterpret_cast<const float2*>(p.env + kFull * H);
+#pragma unroll
+    for (int kk = 0; kk < HS; ++kk) {
+      const float2 e = env_full[lane + 64 * kk];
+      rcp[kk] = make_float2(1.0f / e.x, 1.0f / e.y);
+    }
+  }
+  // hop `hp` from accumulator slots a0, a1: the same two forms as the long-run kernel (reciprocal of the full envelope /
+  // division by the partial one at the clip's two ends)
+  auto emit_regs = [&](long long hp, v2f a0, v2f a1) {
+    float2* dst = reinterpret_cast<float2*>(yclip + (hp - 2) * H);
+    if (hp >= 3 && hp < T) {
+      put_y(dst + lane, make_float2(a0.x * rcp[0].x, a0.y * rcp[0].y));
+      put_y(dst + lane + 64, make_float2(a1.x * rcp[1].x, a1.y * rcp[1].y));
+    } else {
+      int mask = 0;
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const long long tt = hp - (R - 1) + q;
+        if (tt >= 0 && tt < T) mask |= 1 << q;
+      }
+      const float2* env = reinterpret_cast<const float2*>(p.env + mask * H);
+      const float2 e0 = env[lane], e1 = env[lane + 64];
+      put_y(dst + lane, make_float2(a0.x / e0.x, a0.y / e0.y));
+      put_y(dst + lane + 64, make_float2(a1.x / e1.x, a1.y / e1.y));
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int m = 0; m < 8 - HS; ++m) acc[m] = acc[m + HS];
+#pragma unroll
+    for (int m = 8 - HS; m < 8; ++m) acc[m] = (v2f){0.f, 0.f};
+  };
+  float4* park = park_all + wave * 6 * 64 + lane;
+  // any frame: the run's head (pieces parked, hops not yet this wave's), the clip's first hops, the tail of the loads
+  auto generic_step = [&]() {
+    const RawFrame<IN_MODE> cur = q0;
+    q0 = q1;
+    if (t + 2 < t_stop) load_raw(p, fbase + t + 2, lane, q1);
+    v2f v[8];
+    consume(cur, v);
+    const long long i = t - ta;
+    if (parks && i < 3 && t < tb) {
+      // frame ta + i feeds hops ta + i .. ta + 2 of the wave before: slots 0 .. 2 - i, pieces {0,1,2}, {3,4}, {5}
+      const int base = i == 0 ? 0 : (i == 1 ? 3 : 5);
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        if (s < 3 - i) park[(base + s) * 64] = make_float4(v[2 * s].x, v[2 * s].y, v[2 * s + 1].x, v[2 * s + 1].y);
+    }
+    if (t >= pe0 && t < pe1) emit_regs(t, acc[0], acc[1]);
+    advance();
+    ++t;
+  };
+
+  // steady state: own hop, full envelope, frame t + 2 exists and is this wave's to load, nothing to park
+  long long fast_begin = ta + 3 > pe0 ? ta + 3 : pe0;
+  if (fast_begin < 3) fast_begin = 3;
+  long long fast_end = tb - 1;                                       // inclusive; the barrier sits at t == tb
+  if (fast_end > t_stop - 3) fast_end = t_stop - 3;
+  while (t < fast_begin && t < tb) generic_step();
+  if (t <= fast_end) {
+    auto fast_step = [&](RawFrame<IN_MODE>& q) {
+      const RawFrame<IN_MODE> cur = q;
+      load_raw(p, fbase + t + 2, lane, q);
+      v2f v[8];
+      consume(cur, v);
+      float2* dst = reinterpret_cast<float2*>(yclip + (t - 2) * H);
+      put_y(dst + lane, make_float2(acc[0].x * rcp[0].x, acc[0].y * rcp[0].y));
+      put_y(dst + lane + 64, make_float2(acc[1].x * rcp[1].x, acc[1].y * rcp[1].y));
+      advance();
+      ++t;
+    };
+    while (t + 1 <= fast_end) {
+      fast_step(q0);
+      fast_step(q1);
+    }
+  }
+  while (t < tb) generic_step();
+  __syncthreads();                                                   // every wave's pieces are in LDS
+  if (self_cool) {
+    while (t < t_stop) generic_step();                               // the next tile's (or nobody's) first three frames
+    // the clip's last hop has no frame of its own number
+    if (t_stop == T && T >= pe0 && T < pe1 && t == T) emit_regs(T, acc[0], acc[1]);
+  } else if (tb > ta) {
+    // hops tb, tb + 1, tb + 2 (all inside the clip: the next wave holds at least three frames): the next wave's frames
+    // one at a time, oldest first
+    const float4* nx = park_all + (wave + 1) * 6 * 64 + lane;
+    // piece (frame i, slot s) lands in hop i + s; its window samples are those of slot s
+    auto add4 = [&](int hop, int s, const float4 pc) {
+      acc[2 * hop] = __builtin_elementwise_fma((v2f){pc.x, pc.y}, ola_window(win, lane, 2 * s), acc[2 * hop]);
+      acc[2 * hop + 1] = __builtin_elementwise_fma((v2f){pc.z, pc.w}, ola_window(win, lane, 2 * s + 1), acc[2 * hop + 1]);
+    };
+    add4(0, 0, nx[0 * 64]);
+    add4(1, 1, nx[1 * 64]);
+    add4(1, 0, nx[3 * 64]);
+    add4(2, 2, nx[2 * 64]);
+    add4(2, 1, nx[4 * 64]);
+    add4(2, 0, nx[5 * 64]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (tb + s >= pe0) emit_regs(tb + s, acc[2 * s], acc[2 * s + 1]);
+  }
+}
+
 // K5: irFFT + window, frames out (no overlap-add): RealtimeSTFT/RealtimeDGT.invert
 template <int IN_MODE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void irfft1024_frames_kernel(InvParams p) {
@@ -1155,7 +1364,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void irfft1024_frames_kernel(
 // ---------------------------------------------------------------------------
 namespace at_hip {
 
-// pass lengths of the reference's default bank at sr 44100 / n_fft 1024 in quads, one per nibble (band_bank.h)
+// pass lengths of the reference's default bank at sr 44100 / n_fft 1024 in quads, one per nibble (band_bank.h).  The packed
+// epilogue also hard-codes the feature row as 513 floats (its 1-KB block stream): the dispatch below asks for
+// n_filters == 513 as well -- a 514..576-filter bank can have the same nine pass lengths
 constexpr fqp_t kDefaultBankQuads = 0x001111223ull;
 constexpr int kDefaultBankPasses = 9;      // 513 filters: seven passes of walks, two of empty filters
 static bool bank_is(const BandBank* bank, fqp_t fqp, int n_passes) {
@@ -1281,7 +1492,8 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
     // instructions (-31 %) nor fewer write requests (115 -> 96 per frame) nor aligned spectrum blocks moved it
     // (1.25-1.34 ms in every combination, same boxes: profiles/r04_default_bank_513.md).
     if (hop == 256 && !polar && !phase && !feat_channel_major && !out && contrast == 1 && !power2 &&
-        bank_is(bank, kDefaultBankQuads, kDefaultBankPasses) && (((uintptr_t)feat) & 15) == 0 && variant(kVarEpilogue) == 0) {
+        bank->n_filters == F && bank_is(bank, kDefaultBankQuads, kDefaultBankPasses) && (((uintptr_t)feat) & 15) == 0 &&
+        variant(kVarEpilogue) == 0) {
       kernel = stft1024_h256_fwd_kernel<false, 2, 8, true, 0, false, 2, 0, 0, 0, false, false, 0, 1, false, false, kDefaultBankQuads, kDefaultBankPasses>;
       default_bank_fixed = true;
     }
@@ -1399,6 +1611,40 @@ int launch_istft1024_ola(const float2* X, const float* mag, const float* phase, 
     if (!X || !mag) return -1;
     kernel = hop == 128 ? istft1024_ola_kernel<IN_GL, 1, true, 1>
            : hop == 256 ? istft1024_ola_kernel<IN_GL, 1, true, 2> : istft1024_ola_kernel<IN_GL, 1, true, 4>;
+  }
+  // Full batches at the default hop: tiles of consecutive frames per workgroup, dispatched in address order, the overlap
+  // state handed from wave to wave through LDS (istft1024_tile_kernel).  "Full" = at least two tiles for every workgroup
+  // the chip holds; anything smaller keeps the planner's long runs below.  Same bits either way.
+  if (hop == 256 && !gl_tprev && T >= 64 && variant(kVarIstftRuns) == 0) {
+    int nw = 4, occ = 2;
+    long long target = 175;                                  // frames per tile aimed at (same-box A/B of 125 ... 350: gpurun_out r05d)
+    if (const char* e = dev_env("ACIDS_ISTFT_TILE")) {      // dev builds: "<waves>:<frames per tile>[:<waves per SIMD>]", "0" = long runs
+      nw = atoi(e);
+      if (const char* c = strchr(e, ':')) {
+        target = atoll(c + 1);
+        if (const char* c2 = strchr(c + 1, ':')) occ = atoi(c2 + 1);
+      }
+    }
+    if (nw == 4 || nw == 8) {
+      void (*tk)(InvParams) = nw == 8 ? (X ? istft1024_tile_kernel<IN_COMPLEX, 8, 2> : istft1024_tile_kernel<IN_POLAR, 8, 2>)
+                                      : (X ? istft1024_tile_kernel<IN_COMPLEX, 4, 2> : istft1024_tile_kernel<IN_POLAR, 4, 2>);
+      if (nw == 4 && occ == 3) tk = X ? istft1024_tile_kernel<IN_COMPLEX, 4, 3> : istft1024_tile_kernel<IN_POLAR, 4, 3>;
+      if (target < 8 * nw) target = 8 * nw;
+      const long long tiles_per_clip = (T + target - 1) / target;
+      const long long want = (T + tiles_per_clip - 1) / tiles_per_clip;      // frames per tile, balanced over the clip
+      long long n = (want + 3 + nw - 1) / nw;                                // frames per wave; the last wave n - 3
+      if (n < 6) n = 6;
+      const long long tile_frames = nw * n - 3;
+      const long long tpc = (T + tile_frames - 1) / tile_frames;
+      const long long resident = resident_waves(tk, 64 * nw, 0) / nw;
+      if (B * tpc >= 2 * resident && B * tpc < (1LL << 31)) {
+        p.slots_per_run = n;
+        p.frames_per_block = tile_frames;
+        p.runs_per_clip = tpc;
+        hipLaunchKernelGGL(tk, dim3((unsigned)(B * tpc)), dim3(64 * nw), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -5;
+      }
+    }
   }
   // runs of >= 8 hop slots (a run synthesises n_fft/hop - 1 frames more than it emits slots: the planner's overhead term)
   const long long slots = resident_waves(kernel, 64 * WAVES_PER_BLOCK, 0);

@@ -19,7 +19,8 @@ enum {
   kVarScanLayout = 3,       // 0: one block per clip for rows that are not whole 64-byte segments; 1: flattened columns
   kVarPghiKernel = 4,       // 0: cooperative heap kernels (+ rank fast path, realtime); 1: winner-bit offline kernel;
                             // 2: single-lane kernels; 3: cooperative kernels, realtime without the rank fast path
-  kVarCount = 5
+  kVarIstftRuns = 5,        // 1: the n_fft-1024 inverse always as one long run per wave (no workgroup tiles with LDS hand-over)
+  kVarCount = 6
 };
 
 int variant(int which);     // capi.hip

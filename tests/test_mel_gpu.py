@@ -622,3 +622,34 @@ def test_fixed_form_projection_equals_the_fused_epilogue_bit_for_bit(dev, monkey
         with variant("epilogue", 1):
             ref = mag(Xs)
         assert rel_max(cpu(mag(Xs)), cpu(ref)) < 2e-6, rows
+
+
+@pytest.mark.gpu
+def test_packed_epilogue_is_only_taken_by_513_filter_banks(dev):
+    """the packed fixed-length epilogue hard-codes a 513-float feature row, but was selected by the nine pass
+    lengths alone.  A 520-filter bank with exactly the default bank's pass lengths (12, 8, 8, 4, 4, 4, 4, 0, 0 bins: 64
+    filters of three quads, 128 of two, 256 of one, 72 empty) must take the generic epilogue: same features as with
+    `variant("epilogue", 1)`, bit for bit, and as the dense contraction."""
+    from acids_transforms_amd import ops
+    from acids_transforms_amd.utils.banded import BandedBank
+    g = torch.Generator().manual_seed(520)
+    K, N = 513, 520
+    bank = torch.zeros(K, N)
+    quads = [3] * 64 + [2] * 128 + [1] * 256 + [0] * 72
+    perm = torch.randperm(N, generator=g).tolist()
+    for f, nq in zip(perm, quads):
+        if nq:
+            q0 = int(torch.randint(0, (K - 4 * nq) // 4, (1,), generator=g))
+            bank[4 * q0:4 * q0 + 4 * nq, f] = torch.rand(4 * nq, generator=g) + 0.1
+    band = BandedBank(bank)
+    assert band.n_passes == 9 and [int(v) for v in band.pass_len[:9]] == [12, 8, 8, 4, 4, 4, 4, 0, 0] and band.fusable
+    x = (torch.randn(3, 20000, generator=g) * 0.2).to(dev)
+    st = A.STFT().to(dev)
+    eps = float(torch.finfo(torch.float32).eps)
+    _, _, fa = ops.stft_mel_forward(x, st.window[:1024], band, contrast="log1p", eps=eps, want_spectrum=False)
+    with variant("epilogue", 1):
+        _, _, fb = ops.stft_mel_forward(x, st.window[:1024], band, contrast="log1p", eps=eps, want_spectrum=False)
+    assert fa.shape == (3, 79, N)
+    assert torch.equal(fa, fb)
+    want = torch.log1p(torch.matmul(st(x).abs().cpu(), bank))
+    assert rel_max(cpu(fa), want.numpy()) < TOL

@@ -537,3 +537,40 @@ def test_float64_inputs_raise_instead_of_being_narrowed(dev):
         with pytest.raises(A.AcidsHipError, match="float64|complex128"):
             call()
     assert rel_max(cpu(st(x.half())), cpu(st(x.half().float()))) == 0.0
+
+
+def test_tiled_inverse_is_the_long_run_inverse_bit_for_bit(dev):
+    """Round 5: full batches take istft1024_tile_kernel (a workgroup owns a tile of consecutive frames, the overlap state
+    crosses the cuts between its waves through LDS, additions in frame order); `variant("istft_runs", 1)` forces the
+    long-run kernel.  Every frame count from 64 to 300 -- every remainder of the tile and of a wave's share, clip ends
+    inside the first, middle and last wave of a tile, last waves holding 0, 1, 2 frames -- complex and polar input, STFT
+    and DGT windows: identical bits, and the long-run kernel is the one the goldens and the oracle pin."""
+    from acids_transforms_amd import ops
+    g = torch.Generator(device=dev).manual_seed(77)
+    st = A.STFT().to(dev)
+    dg = A.DGT().to(dev)
+    B = 600                                   # >= two tiles per workgroup the chip holds, at every T below
+    Xall = torch.randn(B, 300, 513, 2, device=dev, generator=g)
+    for T in list(range(64, 300)) + [300]:
+        X = torch.view_as_complex(Xall[:, :T].contiguous())
+        mod = st if T % 2 else dg
+        y_tile = mod.invert(X)
+        with variant("istft_runs", 1):
+            y_runs = mod.invert(X)
+        assert y_tile.shape == (B, 256 * (T - 1))
+        assert torch.equal(y_tile, y_runs), T
+    for T in (64, 117, 118, 119, 120, 233, 234, 235):
+        mag = Xall[:, :T, :, 0].abs().contiguous()
+        ph = (Xall[:, :T, :, 1] * 3e4).contiguous()
+        w = dg.inv_window[:1024]
+        y_tile = ops.istft(None, w, 1024, 256, env16=dg._env16, mag=mag, phase=ph)
+        with variant("istft_runs", 1):
+            y_runs = ops.istft(None, w, 1024, 256, env16=dg._env16, mag=mag, phase=ph)
+        assert torch.equal(y_tile, y_runs), T
+    # and the tiled kernel itself against the oracle at the bench size's frame count
+    x = torch.randn(600, 176400, device=dev, generator=g) * 0.1
+    X = st(x)
+    y = st.invert(X)
+    ids = [0, 299, 599]
+    yr = O.istft(X[ids].cpu(), O.hann_window(1024), 1024, 256)
+    assert rel_max(cpu(y[ids]), yr.numpy()) < TOL
