@@ -1536,6 +1536,13 @@ int launch_stft1024_h256_fwd(const float* x, long long B, long long L, long long
         kernel = stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2, true, true, 0, 1, false, true>;
         persistent = true;
       }
+#ifdef AT_DEV_SWITCHES
+      // dev A/B (round 5, energy): pass twiddles (1) / + window (3) in registers, three waves per SIMD in 4-wave blocks
+      if (const char* e = dev_env("ACIDS_FWD_HYB")) {
+        if (atoi(e) == 1) { kernel = stft1024_h256_fwd_kernel<false, 1, 4, true, 0, false, 2, 2, 8, 2, true, true, 1>; NW = 4; }
+        if (atoi(e) == 3) { kernel = stft1024_h256_fwd_kernel<false, 1, 4, true, 0, false, 2, 2, 8, 2, true, true, 3>; NW = 4; }
+      }
+#endif
     }
     // Features only (the spectrum never stored) is bound by the LDS and by instruction issue, not by HBM: with both
     // pass-twiddle tables and the window in registers (HYB = 3: 30 fewer LDS reads per frame) at three waves per SIMD --

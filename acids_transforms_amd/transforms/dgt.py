@@ -154,6 +154,11 @@ class RealtimeDGT(DGT):
     def set_batch_size(self, batch_size: Union[int, List[int]]):
         self.reset(batch_size)
 
+    def batch_size(self) -> List[int]:
+        """The reference declares this method (dgt.py:271-273) and then shadows it on every instance with the attribute
+        of the same name set in __init__ / reset(); kept for the class's surface."""
+        return self.hgi_mag_buffer.shape[:-2]
+
     def reset(self, batch_size: Union[int, List[int]]) -> None:
         self.batch_size = [batch_size] if isinstance(batch_size, int) else torch.Size(batch_size)
         dev = self.window.device
@@ -179,6 +184,7 @@ class RealtimeDGT(DGT):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._follow(x)
+        self._release_phase_source()
         x_dgt = self._rt_forward(x)
         self._replace_phase_buffer(x_dgt)
         return x_dgt

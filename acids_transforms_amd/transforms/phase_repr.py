@@ -270,6 +270,7 @@ class SpectralRepresentation(AudioTransform):
         m_off, m_sc = mag._affine()
         p_off, p_sc = ph._affine(x)
         xb, batch_shape = reshape_batches(x, -1)
+        stage._release_phase_source()
         y = ops.stft_polar_forward(xb, stage.window[:1024], mag._banded(), mag.contrast_mode, m_off, m_sc, mag._eps,
                                    p_off, p_sc)
         # the stage's phase buffer (keep_input inversion) is the phase half of the result, de-normalised on demand

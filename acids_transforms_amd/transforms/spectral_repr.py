@@ -148,6 +148,7 @@ class Magnitude(AudioTransform):
         self._follow(x)
         off, sc = self._affine()
         xb, batch_shape = reshape_batches(x, -1)
+        stage._release_phase_source()
         X, phase, feat = ops.stft_mel_forward(xb, stage.window[:1024], self._banded(), self.contrast_mode, off, sc,
                                               self._eps, want_phase=stage.eager_phase, hop=stage._hop)
         stage._replace_phase_buffer(X, phase)

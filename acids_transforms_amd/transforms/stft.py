@@ -196,6 +196,14 @@ class STFT(AudioTransform):
         self._buffers["_env16"] = self._make_env16().to(self._buffers["window"].device)
         return out
 
+    def _release_phase_source(self) -> None:
+        """Called by every forward right before it allocates its output: the spectrum the LAST forward parked for the lazy
+        phase_buffer is about to be superseded, so let go of it first.  Otherwise the new spectrum is allocated while the
+        old one is still referenced: 2.9 GB held for nothing at the bench size, and the caching allocator hands out two
+        blocks in turn -- the period-2 alternation of step times (the blocks are not equally fast: +2.4 % on the forward,
+        tools/step_probe.py `ptrs` against `hold`, profiles/r05_power_clock.md)."""
+        self.__dict__["_phase_src"] = None
+
     def _replace_phase_buffer(self, spectrum: Optional[torch.Tensor], phase: Optional[torch.Tensor] = None) -> None:
         if phase is not None:
             self.__dict__["_phase_src"] = None
@@ -215,6 +223,7 @@ class STFT(AudioTransform):
         self._follow(x)
         x, batch_shape = reshape_batches(x, -1)
         window = self.window[:self._n_fft]
+        self._release_phase_source()
         if self.eager_phase:
             x_fft, phase = ops.stft_forward(x, window, self._n_fft, self._hop, center=True, want_phase=True)
             self._replace_phase_buffer(None, phase)
@@ -376,6 +385,7 @@ class RealtimeSTFT(STFT):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._follow(x)
+        self._release_phase_source()
         x_fft = self._rt_forward(x)
         self._replace_phase_buffer(x_fft)
         return x_fft

@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--pghi-clips", type=int, default=1024, help="clips for the DGT+PGHI round-trip side measurement")
     ap.add_argument("--streams", type=int, default=256, help="concurrent streams for the RealtimeDGT side measurement")
     ap.add_argument("--stream-steps", type=int, default=1000, help="steps per cell of the streaming matrix")
+    ap.add_argument("--dry-plan", action="store_true",
+                    help="print, WITHOUT touching a GPU or importing torch, what `--gpus N` will do: rank -> device map, clip "
+                         "ranges per rank, wire bytes per rank of the three configs[3] figures, timeouts, the keys of the line")
     return ap.parse_args()
 
 
@@ -114,6 +117,66 @@ def visible_gpu_count() -> int:
     return visible_gpu_census()[0]
 
 
+HOOK_VARS = ("ACIDS_BENCH_CORRUPT", "ACIDS_BENCH_INJECT_FAILURE", "ACIDS_BENCH_FORCE_DIST", "ACIDS_BENCH_REHEARSAL")
+
+
+def hooks_armed():
+    """Test-only switches of this program that are set in the environment: printed into the JSON line, so that a line
+    measured with one of them armed cannot pass for a clean one."""
+    return sorted(v for v in HOOK_VARS if os.environ.get(v))
+
+
+def dist_timeout_s():
+    return int(os.environ.get("ACIDS_BENCH_DIST_TIMEOUT", "180"))
+
+
+def dry_plan(args):
+    """What `python bench.py --gpus N [--pipeline config4]` will do, computed from the arguments alone (no torch, no
+    HIP): the first-run-proof sheet for a node nobody has been able to rehearse on."""
+    n, B = args.gpus, args.batch
+    T, F, n_mels, n_mfcc = 1 + (4 * 44100) // 256, 513, 128, 40
+    ndev, definite = visible_gpu_census()
+    feat_elems = B * T * (n_mels + n_mfcc)
+    plan = {
+        "dry_plan": True, "n_gpus": n, "visible_devices": ndev, "visible_devices_definite": definite,
+        "launcher": "this process starts %d children (RANK = LOCAL_RANK = 0..%d, MASTER_ADDR 127.0.0.1, a free MASTER_PORT) "
+                    "unless WORLD_SIZE is already set (torch.distributed.run), in which case the launcher's ranks are used" % (n, n - 1),
+        "backend": "nccl (RCCL over xGMI), init_process_group(device_id=cuda:LOCAL_RANK, timeout=%d s)" % dist_timeout_s(),
+        "timeout_s": dist_timeout_s(),
+        "rank_to_device": {str(r): "cuda:%d" % r for r in range(n)},
+        "scaling": "weak: %d clips x 4 s per GPU, %d clips in all" % (B, n * B),
+        "clip_ranges": {str(r): [r * B, (r + 1) * B] for r in range(n)},
+        "frames_per_rank_per_step": B * T,
+        "headline_step": {"per_rank": "fused STFT + Magnitude(mel=128) -> ISTFT on the rank's own clips; no data-path collective",
+                          "collectives_in_timed_region": ["all_reduce(MIN) of the ranks' verdicts: the barrier on both sides",
+                                                          "all_reduce(MAX) of the elapsed time"],
+                          "value": "n_gpus x clips x 690 x steps / max-over-ranks elapsed"},
+        "config4": {"workload": "configs[3]: %d clips in all (%d per GPU): fused STFT + log-mel128 (spectrum never stored) -> "
+                                "DCT-II 40, features reassembled with all_gather_into_tensor" % (n * B, B),
+                    "figures": ["compute_only", "with_allgather_fp32", "with_allgather_bf16_wire", "with_allgather_mfcc40_only_fp32"],
+                    "wire_bytes_sent_per_rank_per_step": {
+                        "with_allgather_fp32": 4 * feat_elems, "with_allgather_bf16_wire": 2 * feat_elems,
+                        "with_allgather_mfcc40_only_fp32": 4 * B * T * n_mfcc},
+                    "gathered_bytes_per_rank_per_step": {
+                        "with_allgather_fp32": 4 * feat_elems * n, "with_allgather_bf16_wire": 2 * feat_elems * n,
+                        "with_allgather_mfcc40_only_fp32": 4 * B * T * n_mfcc * n},
+                    "where": "the headline line carries them under `config4` (run on all ranks before any rank-0-only leg); "
+                             "`--pipeline config4` makes with_allgather_fp32 the line's `value`"},
+        "commands": {"driver": "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P "
+                               "bench.py --gpus %d --steps K --warmup W" % (n, n),
+                     "self_launch": "python bench.py --gpus %d --steps K --warmup W" % n},
+        "line_keys": ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                      "vs_baseline", "dtype", "data", "config", "world_size_observed", "backend", "roofline", "kernels",
+                      "config4", "hooks_armed", "verification"],
+        "exit_status": {"0": "measured and verified", "2": "WORLD_SIZE != --gpus / no ROCm device", "3": "fewer devices than ranks",
+                        "4": "a side leg raised", "5": "a spot check of timed output failed", "6": "a rank failed inside a timed region"},
+        "hooks_armed": hooks_armed(),
+    }
+    if definite and ndev < n:
+        plan["would_refuse"] = "--gpus %d asked for, %d ROCm device(s) visible" % (n, ndev)
+    return plan
+
+
 def launch_ranks(args) -> int:
     n = args.gpus
     rehearsal = os.environ.get("ACIDS_BENCH_REHEARSAL") == "1"
@@ -125,8 +188,10 @@ def launch_ranks(args) -> int:
     port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
     procs = []
     for r in range(n):
+        # the children inherit the environment as it is (this image exports HSA_ENABLE_IPC_MODE_LEGACY=0 itself: RCCL's
+        # peer buffers need dmabuf IPC here; it is not for this program to set or unset)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     alive = list(procs)
@@ -156,6 +221,9 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
     # has provably never initialised the GPU (torch.cuda.device_count() falls back to hipGetDeviceCount() when amdsmi
     # is unavailable, and a process that has made a HIP call must not start further GPU processes on this pool).
     _args = parse()
+    if _args.dry_plan:
+        print(json.dumps(dry_plan(_args)))
+        sys.exit(0)
     if _args.gpus > 1:
         sys.exit(launch_ranks(_args))
 
@@ -177,6 +245,71 @@ BYTES_ISTFT = F_BINS * 8 + HOP * 4               # 5128
 BYTES_MEL = F_BINS * 8 + N_MELS * 4              # 4616 (unfused: reads the complex spectrum)
 BYTES_FUSED_FEATURES_ONLY = HOP * 4 + N_MELS * 4  # 1536 (spectrum never stored)
 FLOPS_MEL = 2 * F_BINS * N_MELS                  # 131328 dense
+
+
+# ----------------------------------------------------------------------------------------------
+# socket power / shader clock next to the timed kernels (sysfs hwmon of the device; plain file reads from a side thread)
+# ----------------------------------------------------------------------------------------------
+def device_hwmon(index):
+    """hwmon directory of HIP device `index` (PCI bus id from the runtime -> /sys/bus/pci/devices/<bdf>/hwmon/hwmon*), or None."""
+    import ctypes
+    import glob
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, index) != 0:
+            return None
+        hits = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % buf.value.decode().lower())
+        return hits[0] if hits and os.path.exists(os.path.join(hits[0], "power1_input")) else None
+    except Exception:
+        return None
+
+
+class PowerSampler:
+    """(time, watts, sclk MHz) every 10 ms while running.  The step is power-managed: at 1024 clips both kernels sit on the
+    socket's power cap and the shader clock is what the controller leaves them (profiles/r05_power_clock.md)."""
+
+    def __init__(self, hwmon, period=0.01):
+        import threading
+        self.hwmon, self.period, self.rows, self.stop = hwmon, period, [], False
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        try:
+            fp = open(os.path.join(self.hwmon, "power1_input"))
+            ff = open(os.path.join(self.hwmon, "freq1_input"))
+        except OSError:
+            return
+        while not self.stop:
+            try:
+                fp.seek(0)
+                ff.seek(0)
+                self.rows.append((time.perf_counter(), int(fp.read()) * 1e-6, int(ff.read()) * 1e-6))
+            except (OSError, ValueError):
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.hwmon:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        return False
+
+    def window(self, t0, t1):
+        rows = [r for r in self.rows if t0 <= r[0] <= t1]
+        if not rows:
+            return None
+        return {"samples": len(rows), "watts": sum(r[1] for r in rows) / len(rows), "sclk_mhz": sum(r[2] for r in rows) / len(rows),
+                "sclk_mhz_min": min(r[2] for r in rows)}
+
+    def cap_watts(self):
+        try:
+            return int(open(os.path.join(self.hwmon, "power1_cap")).read()) * 1e-6
+        except Exception:
+            return None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -354,6 +487,9 @@ class LegFailed(RuntimeError):
 # ----------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.dry_plan:
+        print(json.dumps(dry_plan(args)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))          # (imported and called as a function; the script path launched above)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -395,7 +531,7 @@ def main():
             # an explicit timeout: a rank that dies (or never issues its half of a collective) turns into an error on
             # the others after this long instead of a hang -- the parent / torchrun then ends the job non-zero
             import datetime
-            limit = datetime.timedelta(seconds=int(os.environ.get("ACIDS_BENCH_DIST_TIMEOUT", "180")))
+            limit = datetime.timedelta(seconds=dist_timeout_s())
             if rehearsal:
                 dist.init_process_group("gloo", timeout=limit)
             else:
@@ -531,7 +667,9 @@ def main():
         t_compute = timed_region(config4_compute, steps, warmup, "config4 compute")
         res["compute_only"] = {"frames_per_s": world * frames_per_step * steps / t_compute,
                                "ms_per_step": t_compute / steps * 1e3}
-        if use_dist and not rehearsal:
+        if use_dist:
+            # rehearsal (gloo, every rank on cuda:0): gloo gathers host tensors only, so the wire tensor is staged through the
+            # host there -- the control flow (side stream, one gather in flight, wire dtype, handles) is the real one
             comm = torch.cuda.Stream(device=dev)
 
             def with_gather(wire_dtype, what):
@@ -549,6 +687,8 @@ def main():
                         for t in ((logmel, coef) if what == "mel128+mfcc40" else (coef,)):
                             t.record_stream(comm)
                             wire = t if wire_dtype is None else t.to(wire_dtype)
+                            if rehearsal:
+                                wire = wire.cpu()
                             _, h = all_gather_features(wire, world * B, async_op=True)
                             if h is not None:
                                 pending.append(h)
@@ -575,7 +715,7 @@ def main():
         """A collective leg of the headline failed somewhere: every rank is here (LegFailed is raised on all of them),
         rank 0 says so on stdout, everybody exits non-zero."""
         if rank == 0:
-            print(json.dumps({"error": "rank failure inside a timed region: %s" % exc, "n_gpus": world}))
+            print(json.dumps({"error": "rank failure inside a timed region: %s" % exc, "n_gpus": world, "hooks_armed": hooks_armed()}))
             sys.stdout.flush()
         if use_dist:
             dist.destroy_process_group()
@@ -599,7 +739,7 @@ def main():
                        "n_fft": N_FFT, "hop": HOP, "frames_per_clip": T_FRAMES, "clips_per_gpu": B,
                        "sharding": "clips; all-gather only to reassemble outputs"},
             "world_size_observed": dist.get_world_size() if use_dist else 1, "backend": backend,
-            "config4": c4,
+            "config4": c4, "hooks_armed": hooks_armed(),
         }
         if rank == 0:
             print(json.dumps(result))
@@ -717,7 +857,7 @@ def main():
     def hbm_entry(name, bytes_per_frame, ms=None):
         ms = avg[name] if ms is None else ms
         a = frames_per_step * bytes_per_frame / (ms * 1e-3) / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"kernel": name, "key": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(ms, 4), "algorithmic_bytes_per_frame": bytes_per_frame}
 
     def timed_ms(fn, n=10, warm=3):
@@ -792,7 +932,84 @@ def main():
                           "frac": None if step_gbs is None else round(step_gbs / HBM_PEAK_GBS, 4),
                           "note": "both kernels of the step over the step's wall time (launch gaps included), per GPU"}
 
+    # The same as SCALAR members of `roofline` (the driver's record keeps the scalar members and only the names of
+    # everything nested): the step's other kernel, the forms outside the step, the whole step, even / odd steps
+    by_key = {kk["key"]: kk for kk in kernels}
+    roof.pop("key", None)
+    for key, short in (("stft_fwd", "fused_fwd" if fused else "fwd"), ("istft", "istft"), ("stft_fwd_plain", "plain_fwd"),
+                       ("fwd_features_only", "features_only"), ("fused_mel513", "fused_mel513"),
+                       ("fwd_features_only_mel513", "features_only_mel513"), ("mel", "mel_standalone")):
+        if key in by_key:
+            roof[short + "_ms"] = by_key[key]["ms"]
+            roof[short + "_frac"] = by_key[key]["frac"]
+    roof["whole_step_ms"] = round(ms_per_step, 4)
+    roof["whole_step_frac"] = None if step_gbs is None else round(step_gbs / HBM_PEAK_GBS, 4)
+    ev_, od_ = step_ms_events[0::2], step_ms_events[1::2]
+    roof["step_even_ms"] = round(sum(ev_) / len(ev_), 4)
+    roof["step_odd_ms"] = round(sum(od_) / len(od_), 4) if od_ else None
+
     # -- side measurements -----------------------------------------------------------------------------------
+    def extra_pattern_copy():
+        """What the memory system gives the step's two ACCESS PATTERNS on this box, in this process: copy kernels with the
+        forward's (audio in, 512-byte aligned blocks of the spectrum stream + 128 features out) and the inverse's (spectrum
+        rows in, hops out) streams and no arithmetic, waves taking 8-frame runs in dispatch order (tools/ubench/pattern_lib.hip,
+        the kernels of stream_pattern3.hip).  The ceiling the product kernels are compared with -- not torch's copy_."""
+        import ctypes
+        so = os.path.join(ROOT, "tools", "ubench", "libpattern.so")
+        if not os.path.exists(so):
+            raise RuntimeError("tools/ubench/libpattern.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+        h = ctypes.CDLL(so)
+        V, I64, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        h.pat_fwd.argtypes = [V, V, V, I64, I, I, V]
+        h.pat_inv.argtypes = [V, V, I64, I, I, V]
+        from acids_transforms_amd._lib import stream_ptr
+        Xb = torch.empty((B, T_FRAMES, F_BINS), dtype=torch.complex64, device=dev)
+        fb = torch.empty((B, T_FRAMES, N_MELS), dtype=torch.float32, device=dev)
+        yb = torch.empty((B * T_FRAMES * HOP,), dtype=torch.float32, device=dev)
+        xb = torch.zeros((B * T_FRAMES * HOP + 1024,), dtype=torch.float32, device=dev)
+        res = {}
+        for G in (8, 173):
+            f_ms = timed_ms(lambda: h.pat_fwd(xb.data_ptr(), Xb.data_ptr(), fb.data_ptr(), frames_per_step, G, 4, stream_ptr()), 30, 25)
+            i_ms = timed_ms(lambda: h.pat_inv(Xb.data_ptr(), yb.data_ptr(), frames_per_step, G, 4, stream_ptr()), 30, 25)
+            res["G%d" % G] = {"fwd_ms": round(f_ms, 4), "inv_ms": round(i_ms, 4)}
+        res["note"] = ("pattern-only copy kernels, dispatch order, 4 waves per workgroup, G frames per wave; G = 8 is the "
+                       "compact write front (best case), G = 173 the product kernels' run length at this batch")
+        return res
+
+    def extra_power():
+        """Socket power and shader clock while the step runs (1 s of steps after the timed region; the sampler is a side
+        thread reading two sysfs files every 10 ms)."""
+        hw = device_hwmon(local_rank)
+        if hw is None:
+            return {"available": False}
+        with PowerSampler(hw) as ps:
+            out = {"available": True, "cap_watts": ps.cap_watts()}
+            X0 = stft(x)
+            legs = [("step", step)]
+            if fused:
+                legs += [("fused_fwd", lambda: mag.forward_fused(stft, x, return_spectrum=True)), ("istft", lambda: stft.invert(X0))]
+            for name, fn in legs:
+                for _ in range(30):
+                    fn()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n = 0
+                while time.perf_counter() - t1 < 1.0:
+                    for _ in range(20):
+                        fn()
+                    n += 20
+                    torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                w = ps.window(t1 + 0.25, t2)
+                if w:
+                    ms = (t2 - t1) / n * 1e3
+                    w.update({"ms": round(ms, 4), "microjoules_per_frame": round(w["watts"] * ms * 1e-3 / frames_per_step * 1e6, 4)})
+                    out[name] = {k: (round(v, 1) if isinstance(v, float) and k != "microjoules_per_frame" and k != "ms" else v)
+                                 for k, v in w.items()}
+            last.clear()
+            del X0
+        return out
+
     def extra_h2d_inclusive():
         # the boundary handed host buffers: H2D of the audio + the step + D2H of features and audio (pinned memory)
         xh = torch.empty(B, CLIP_LEN, pin_memory=True)
@@ -1048,6 +1265,9 @@ def main():
         guarded("config4", lambda: config4_figures(max(10, args.steps // 5), 3))
     if rank == 0:
         guarded("parity_spot_check", parity_spot_check)          # CPU oracle on three clips of the last timed step
+    if rank == 0 and world == 1:
+        guarded("pattern_copy", extra_pattern_copy)               # ~1 s: kept under --no-extras too
+        guarded("power", extra_power)
     if not args.no_extras:
         if rank == 0 and world == 1:
             guarded("hbm_probe", extra_hbm_probe)
@@ -1072,6 +1292,7 @@ def main():
                    "n_fft": N_FFT, "hop": HOP, "frames_per_clip": T_FRAMES, "clips_per_gpu": B,
                    "sharding": "clips, no data-path collective"},
         "world_size_observed": dist.get_world_size() if use_dist else 1, "backend": backend,
+        "hooks_armed": hooks_armed(),
         "roofline": roof,
         "kernels": kernels,
         "settle_steps": settled,
@@ -1083,6 +1304,21 @@ def main():
                           "note": "per-step kernel time (HIP events) inside the timed region: flat = steady state"},
     }
     result.update(extras)
+    if "pattern_copy" in extras:
+        pc = extras["pattern_copy"]
+        roof["pattern_copy_fwd_ms"], roof["pattern_copy_inv_ms"] = pc["G8"]["fwd_ms"], pc["G8"]["inv_ms"]
+        roof["pattern_copy_fwd_long_runs_ms"], roof["pattern_copy_inv_long_runs_ms"] = pc["G173"]["fwd_ms"], pc["G173"]["inv_ms"]
+        roof["achieved_vs_pattern_copy"] = round((pc["G8"]["fwd_ms"] if dominant == "stft_fwd" else pc["G8"]["inv_ms"]) / roof["ms"], 4)
+        if fused:
+            roof["step_vs_pattern_copy"] = round((pc["G8"]["fwd_ms"] + pc["G8"]["inv_ms"]) / ms_per_step, 4)
+    if extras.get("power", {}).get("available"):
+        pw = extras["power"]
+        roof["power_cap_watts"] = pw.get("cap_watts")
+        for leg in ("step", "fused_fwd", "istft"):
+            if leg in pw:
+                roof[leg + "_socket_watts"] = pw[leg]["watts"]
+                roof[leg + "_sclk_mhz"] = pw[leg]["sclk_mhz"]
+                roof[leg + "_microjoules_per_frame"] = pw[leg]["microjoules_per_frame"]
     if "hbm_probe" in extras:
         # the pool's boxes differ by up to 9 % on the step kernels and that spread follows what each box gives a MIXED
         # read / write stream (torch copy_: 4.77 ... 5.07 TB/s), not its write-only or read-only rate (fill_ / sum: equal
@@ -1131,7 +1367,8 @@ def main():
         print(json.dumps(result))
         sys.stdout.flush()
     if use_dist:
-        # every rank arrives with the same keys (collective legs fail on all ranks together), hence the same status
+        # collective legs fail on all ranks together; the spot checks run on rank 0 only, so only rank 0 can leave with
+        # status 5 -- the launcher (launch_ranks / torchrun) relays any non-zero rank
         dist.destroy_process_group()
     if unverified:
         sys.stderr.write("bench.py: spot check(s) of timed results FAILED: %s\n" % ", ".join(unverified))

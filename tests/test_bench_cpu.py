@@ -54,3 +54,27 @@ def test_launcher_refuses_only_a_definite_undercount(monkeypatch, tmp_path):
     assert d2 and n2 <= 3
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
     assert bench.visible_gpu_census()[0] <= 1
+
+
+def test_dry_plan_prints_the_multi_gpu_sheet_without_torch():
+    """`bench.py --gpus 8 --dry-plan` runs in a process that never imports torch and prints the rank ->
+    device map, the clip ranges of configs[3] (8192 / 8), the wire bytes of the three figures and the timeout."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '8', '--dry-plan']\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    assert e.code in (0, None)\n"
+            "assert 'torch' not in sys.modules\n" % os.path.join(ROOT, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 0, r.stderr[-1500:]
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["dry_plan"] and plan["n_gpus"] == 8
+    assert plan["rank_to_device"]["7"] == "cuda:7" and plan["clip_ranges"]["7"] == [7168, 8192]
+    per_rank = 1024 * 690 * (128 + 40)
+    wire = plan["config4"]["wire_bytes_sent_per_rank_per_step"]
+    assert wire == {"with_allgather_fp32": 4 * per_rank, "with_allgather_bf16_wire": 2 * per_rank,
+                    "with_allgather_mfcc40_only_fp32": 4 * 1024 * 690 * 40}
+    assert plan["config4"]["gathered_bytes_per_rank_per_step"]["with_allgather_fp32"] == 8 * 4 * per_rank
+    assert plan["timeout_s"] == 180 and "torch.distributed.run" in plan["commands"]["driver"]
+    assert plan["hooks_armed"] == []

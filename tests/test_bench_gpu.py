@@ -36,11 +36,19 @@ def test_a_failed_spot_check_fails_the_bench():
     assert any("istft" in o["kernel"] for o in line["roofline"]["others"])
     assert any("mel513" in o["kernel"] for o in line["roofline"]["others"])
     assert line["fresh_process_ms_per_step"] > 0
+    # the driver keeps only SCALAR members of `roofline` -- everything it needs is there as scalars
+    roof = line["roofline"]
+    for key in ("istft_ms", "istft_frac", "fused_fwd_ms", "plain_fwd_ms", "plain_fwd_frac", "features_only_ms", "whole_step_ms",
+                "whole_step_frac", "step_even_ms", "step_odd_ms", "pattern_copy_fwd_ms", "pattern_copy_inv_ms",
+                "achieved_vs_pattern_copy"):
+        assert isinstance(roof.get(key), float), key
+    assert line["hooks_armed"] == []
     r, _ = _bench(SMALL + ["--no-extras"], {"ACIDS_BENCH_CORRUPT": "feat"})
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert r.returncode == 5, (r.returncode, r.stderr[-2000:])
     assert line["verification"]["spot_checks_failed"] == ["parity_spot_check"] and not line["parity_spot_check"]["ok"]
     assert line["value"] > 0                                   # the line itself is complete
+    assert line["hooks_armed"] == ["ACIDS_BENCH_CORRUPT"]
 
 
 def test_two_rank_rehearsal_leaves_together_when_one_rank_fails():
@@ -54,6 +62,12 @@ def test_two_rank_rehearsal_leaves_together_when_one_rank_fails():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["world_size_observed"] == 2 and "compute_only" in line["config4"]
+    # the three configs[3] figures of SURVEY 8e and the wire size are in the N > 1 line (gathers staged through the host
+    # under gloo: the control flow is the real one), and the line says which test hooks were armed
+    for key in ("with_allgather_fp32", "with_allgather_bf16_wire", "with_allgather_mfcc40_only_fp32"):
+        assert line["config4"][key]["frames_per_s"] > 0, key
+    assert line["config4"]["wire_bytes_per_rank_fp32"] == 8 * 690 * (128 + 40) * 4
+    assert line["hooks_armed"] == ["ACIDS_BENCH_REHEARSAL"]
     r, dt = _bench(argv, dict(env, ACIDS_BENCH_INJECT_FAILURE="1:config4"))
     assert r.returncode != 0 and dt < 120, (r.returncode, dt)
     line = json.loads(r.stdout.strip().splitlines()[-1])
