@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("ACIDS_HIP_LIB") or os.path.join(_HERE, "libacids_hip.so")   # override: kernel A/B experiments
 
 ABI_VERSION = 4            # what this binding was written against (include/acids_hip.h, at_abi_version())
+# return codes (include/acids_hip.h)
+AT_OK, AT_EINVAL, AT_EUNSUPPORTED, AT_ENOTINIT, AT_EWORKSPACE, AT_ELAUNCH = 0, -1, -2, -3, -4, -5
 
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_i64 = ctypes.c_int64

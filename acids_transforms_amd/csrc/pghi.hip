@@ -1544,7 +1544,10 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
       lds_sync();
       unsigned qbits = bm[lane];          // the frontier, by rank: lane i holds ranks 32 i .. 32 i + 31
       unsigned bav = bm[64 + lane];       // row-f entries that are live and not yet visited, by rank
-      float* rec_phase = reinterpret_cast<float*>(recs);      // rec_phase[4 r] = phase of rank r
+      // rec_word[4 r] = phase of rank r as its bit pattern: written through the SAME type the records are read with (int4
+      // words), so the compiler may not reorder the lane-0 store against the next pop's 16-byte load (a float*
+      // alias of the int4 records relied on in-order DS issue only)
+      int* rec_word = reinterpret_cast<int*>(recs);
       auto bit_of = [&](unsigned bits, int i) -> bool {
         return (((unsigned)__builtin_amdgcn_readlane((int)bits, i >> 5)) >> (i & 31)) & 1u;
       };
@@ -1570,8 +1573,8 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
         const unsigned wd = (unsigned)__builtin_amdgcn_readlane((int)bav, (rd >> 5) & 63);
         const bool up = ru != 0xffff && ((wu >> (ru & 31)) & 1u);
         const bool dn = rd != 0xffff && ((wd >> (rd & 31)) & 1u);
-        if (up && lane == 0) rec_phase[4 * ru] = pk + __int_as_float(rec.z);
-        if (dn && lane == 0) rec_phase[4 * rd] = pk - __int_as_float(rec.w);
+        if (up && lane == 0) rec_word[4 * ru] = __float_as_int(pk + __int_as_float(rec.z));
+        if (dn && lane == 0) rec_word[4 * rd] = __float_as_int(pk - __int_as_float(rec.w));
         const unsigned mu = up ? (1u << (ru & 31)) : 0u, md = dn ? (1u << (rd & 31)) : 0u;
         const unsigned add = ((lane == (ru >> 5)) ? mu : 0u) | ((lane == (rd >> 5)) ? md : 0u);
         qbits |= add;                       // the reached entries join the frontier ...
@@ -1653,7 +1656,7 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
       fast_done = ok;
       lds_sync();
       if (ok) {                             // back to bin order
-        for (int k = lane; k < F; k += 64) ph1[k] = rec_phase[4 * roe[F + k]];
+        for (int k = lane; k < F; k += 64) ph1[k] = __int_as_float(rec_word[4 * roe[F + k]]);
         lds_sync();
       }
     }

@@ -6,16 +6,41 @@ current torch stream.  No arithmetic happens in Python.
 """
 import torch
 
-from ._lib import AcidsHipError, check, device_scoped, lib, ptr, require_device, stream_ptr
+from ._lib import AT_EUNSUPPORTED, AcidsHipError, check, device_scoped, lib, ptr, require_device, stream_ptr
+
+
+_FP64_NARROWING = False
+
+
+class allow_fp64_narrowing:
+    """Opt-in for call sites written against the reference that hand over float64 audio (numpy / soundfile default) or
+    complex128 spectra: `acids_transforms_amd.allow_fp64_narrowing(True)` (process-wide), or as a context manager
+    `with allow_fp64_narrowing(): ...`.  Operands are then narrowed to float32 / complex64 on entry and RESULTS ARE
+    FLOAT32 -- the reference would have stayed in double (stft.py:36-47, torch.stft promotes).  Off by default: a silent
+    loss of digits is an error here (documented divergence with an explicit way in)."""
+
+    def __init__(self, enabled: bool = True):
+        global _FP64_NARROWING
+        self.prev = _FP64_NARROWING
+        _FP64_NARROWING = bool(enabled)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        global _FP64_NARROWING
+        _FP64_NARROWING = self.prev
+        return False
 
 
 def _no_fp64(t, what="input"):
     """The kernels compute in fp32 / complex64.  The reference run on float64 data stays in double precision
     (torch.stft promotes: complex128 out, reference stft.py:98-104); narrowing that silently would hand back fewer
     digits than the caller asked for, so it is an error with the way out in the message."""
-    if t.dtype in (torch.float64, torch.complex128):
+    if t.dtype in (torch.float64, torch.complex128) and not _FP64_NARROWING:
         raise AcidsHipError("%s is %s: the MI355X kernels compute in float32 / complex64 and do not narrow silently -- "
-                            "convert explicitly (x.float() / X.to(torch.complex64)) if single precision is acceptable"
+                            "convert explicitly (x.float() / X.to(torch.complex64)), or opt in once with "
+                            "acids_transforms_amd.allow_fp64_narrowing(True), if single precision is acceptable"
                             % (what, str(t.dtype).replace("torch.", "")))
     return t
 
@@ -640,13 +665,13 @@ def polarif_forward(x, band, contrast, mag_offset, mag_scale, eps, method, frame
     if frame_window is not None:
         frame_window = _f32c(frame_window.to(x.device))
         assert frame_window.numel() == T
-    # one pass over the spectrum where the clip-per-block scan applies (>= 64 clips, 256..4096 bins; the library answers
+    # one pass over the spectrum where the clip-per-block scan applies (>= 64 clips, 256..2048 bins; the library answers
     # AT_EUNSUPPORTED otherwise, and under variant("scan_layout", 1)); same bits as the two kernels below
     start, length, woff, w = band.by_filter(x.device)
     err = lib().at_polarif_forward(ptr(x), B, T, F, SCAN_MODES[method], ptr(frame_window), ptr(if_offset), ptr(if_scale),
                                    ptr(start), ptr(length), ptr(woff), ptr(w), w.numel(), contrast_code(contrast),
                                    ptr(mag_offset), ptr(mag_scale), float(eps), ptr(out), stream_ptr())
-    if err != -2:            # AT_EUNSUPPORTED
+    if err != AT_EUNSUPPORTED:
         check(err, "at_polarif_forward")
         return out
     _project_banded(x, 0, band, contrast, False, mag_offset, mag_scale, eps, out, F, 0, ld_out=2 * F)

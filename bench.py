@@ -1161,6 +1161,24 @@ def main():
                 cell["steps_per_s_" + tag] = 1.0 / dt
                 cell["frames_per_s_" + tag] = S * (C // HOP) / dt
                 del sess
+            if C == 256:
+                # the degenerate input kept visible: the SAME hop-sized chunk every step makes row f-1 == row f,
+                # every pop of the rank fast path lands in a tie group that visits its partner and the frame falls back to
+                # the heap -- it pays for the rank pre-pass AND the heap flood (held frames, hop-periodic tones do this)
+                try:
+                    sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=True, mel_bands=N_MELS, mel_dtype="bf16")
+                    for i in range(5):
+                        sess.step(chunks[0])
+                    torch.cuda.synchronize()
+                    nst = max(50, args.stream_steps // 4)
+                    t1 = time.perf_counter()
+                    for i in range(nst):
+                        sess.step(chunks[0])
+                    torch.cuda.synchronize()
+                    cell["ms_per_step_hipgraph_repeated_chunk"] = (time.perf_counter() - t1) / nst * 1e3
+                    del sess
+                except Exception as exc:
+                    cell["error_repeated_chunk"] = repr(exc)[:200]
             rtres["cells"]["chunk_%d" % C] = cell
         rtres["mel"] = "bf16 MFMA projection (v_mfma_f32_32x32x16_bf16, fp32 accumulate), %d log1p mel features per frame" % N_MELS
         return rtres

@@ -354,7 +354,8 @@ int at_phase_scan_strided(const float *X_complex, const float *phase, int64_t B,
  * band_len[f] bins up to the last one (0: empty filter), band_off[f] offset of those weights in band_w (n_w floats;
  * start + len <= F, off + len <= n_w are the caller's to guarantee).  Both halves equal at_mel_project_banded's and
  * at_phase_scan_strided's bit for bit; the spectrum is read once.  One block per clip: AT_EUNSUPPORTED unless B >= 64,
- * 256 <= F <= 4096, rows that are not whole 64-byte segments and a bank whose weights fit LDS beside eight rows --
+ * 256 <= F <= 2048 (two-column clip blocks; the four-column form is not built for the magnitude side), rows that are not whole
+ * 64-byte segments and a bank whose weights fit LDS beside eight rows --
  * the caller then runs those two entry points. */
 int at_polarif_forward(const float *X_complex, int64_t B, int64_t T, int64_t F, int method, const float *frame_window,
                        const float *if_offset, const float *if_scale, const int *band_start, const int *band_len,

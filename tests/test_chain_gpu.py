@@ -239,6 +239,39 @@ def test_config3_at_full_size(dev):
         assert snr_db(want.numpy(), cpu(y[b])) > 40.0
 
 
+def test_config3_at_full_size_dense_noise(dev):
+    """The worst case of configs[2] in the suite itself (it used to be checked by bench.py's spot check
+    only): 1024 clips of white noise x 4 s -- every bin above the tolerance, ~353 k pops and ~2 000 exact magnitude ties
+    per clip, heaps of 16+ levels whose bottom lives in global memory -- in ONE launch.  Clips 0 / 511 / 1023: pop order
+    bit for bit against the exact-heap C oracle, identical visited masks, phases within tolerance, audio by SNR."""
+    B, L = 1024, 176400
+    d = A.DGT(n_fft=1024, hop_length=256, inversion_mode="pghi").to(dev)
+    g = torch.Generator(device=dev).manual_seed(2024)
+    x = torch.randn(B, L, device=dev, generator=g) * 0.1
+    mag = d(x).abs()
+    del x
+    ph, npops, order = ops.pghi_offline(mag, float(d.gamma), 1024, 256, float(d.tolerance), float(d.eps), debug=True)
+    y = d.invert(mag)
+    assert y.shape == (B, 256 * 689) and bool(torch.isfinite(y).all())
+    inv_win = d.inv_window[:1024].cpu()
+    total = 0
+    for b in (0, 511, 1023):
+        m_b = mag[b].cpu()
+        r = O.pghi_offline(m_b, 1024, 256, tol=float(d.tolerance), want_order=True)
+        k = len(r["order"])
+        total += k
+        assert int(npops[b]) == k and k > 0.99 * 690 * 513              # dense: (nearly) every bin is popped
+        assert np.array_equal(cpu(order[b][:k]), r["order"][:, 0] * 513 + r["order"][:, 1])
+        ref_ph = r["phase"]
+        got = cpu(ph[b])
+        assert np.array_equal(got == 0, ref_ph == 0)
+        tol = 1e-3 + 8 * np.spacing(np.abs(ref_ph).astype(np.float32)) + 1e-5 * np.abs(ref_ph)
+        assert np.all(np.abs(got - ref_ph) <= tol)
+        want = O.polar_istft(m_b.unsqueeze(0), T_(ref_ph).unsqueeze(0), inv_win, 1024, 256)[0]
+        assert snr_db(want.numpy(), cpu(y[b])) > 40.0
+    assert total > 1_000_000
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3] per GPU at its literal size: 1024 clips -> MFCC(40) and MFCC() (MelSpectrogram), one launch each
 # ---------------------------------------------------------------------------------------------------------------

@@ -537,6 +537,14 @@ def test_float64_inputs_raise_instead_of_being_narrowed(dev):
         with pytest.raises(A.AcidsHipError, match="float64|complex128"):
             call()
     assert rel_max(cpu(st(x.half())), cpu(st(x.half().float()))) == 0.0
+    # the explicit way in for reference call sites that hand over float64 (numpy / soundfile audio): narrowed on
+    # entry, float32 results, only while the switch is on
+    with A.allow_fp64_narrowing():
+        Xd = st(x.double())
+        assert Xd.dtype == torch.complex64 and torch.equal(Xd, X)
+        assert torch.equal(st.invert(X.to(torch.complex128)), st.invert(X))
+    with pytest.raises(A.AcidsHipError, match="allow_fp64_narrowing"):
+        st(x.double())
 
 
 def test_tiled_inverse_is_the_long_run_inverse_bit_for_bit(dev):

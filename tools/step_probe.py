@@ -360,6 +360,8 @@ def main():
         h.pat_fwd.argtypes = [V, V, V, I64, I, I, V]
         h.pat_inv.argtypes = [V, V, I64, I, I, V]
         h.ek_run.argtypes = [I, I, I, V, V]
+        h.pat_fwd_flags.argtypes = [V, V, V, I64, I, I, I, V]
+        h.pat_inv_flags.argtypes = [V, V, I64, I, I, I, V]
         return h
 
     def powered_loop(fn, seconds=1.2, chunk=20, warm=10):
@@ -394,6 +396,31 @@ def main():
                 name, f["ms_per_launch"], f.get("watts_mean", 0), f.get("sclk_mean", 0), i["ms_per_launch"], i.get("watts_mean", 0),
                 i.get("sclk_mean", 0)), flush=True)
         res["pattern"] = pat
+        del Xb, fb, yb, xb
+
+    if "memflavour" in sections:
+        # Joules of the step's memory streams by store / load flavour (under a power cap the cheapest stream wins, not the
+        # fastest one at full clock): non-temporal vs plain stores, 8- vs 16-byte stores, non-temporal vs plain loads
+        pl = pattern_lib()
+        Xb = torch.empty((B, T, 513), dtype=torch.complex64, device=dev)
+        fb = torch.empty((B, T, 128), dtype=torch.float32, device=dev)
+        yb = torch.empty((B, HOP * (T - 1) + 1024), dtype=torch.float32, device=dev)
+        xb = torch.empty((B * T * HOP + 1024,), dtype=torch.float32, device=dev).normal_()
+        sink = torch.zeros(16, device=dev)
+        base = powered_loop(lambda: pl.ek_run(0, 1024, 500, L.ptr(sink), L.stream_ptr()), seconds=0.8, chunk=5, warm=3).get("watts_mean", 0.0)
+        mf = {"sleeping_grid_watts": base}
+        names = {0: "nt stores", 1: "plain stores", 2: "nt stores, alt", 3: "plain stores, alt"}
+        for G in (173, 16):
+            for flags in (0, 1, 2, 3):
+                f = powered_loop(lambda: pl.pat_fwd_flags(L.ptr(xb), L.ptr(Xb), L.ptr(fb), frames, G, 4, flags, L.stream_ptr()))
+                i = powered_loop(lambda: pl.pat_inv_flags(L.ptr(Xb), L.ptr(yb), frames, G, 4, flags, L.stream_ptr()))
+                for w in (f, i):
+                    w["joules_per_launch_above_sleep"] = (w.get("watts_mean", 0) - base) * w["ms_per_launch"] * 1e-3
+                mf["G%d_flags%d" % (G, flags)] = {"fwd_feat": f, "inv": i}
+                print("memflavour G=%-3d %-18s fwd(alt = 16-B stores) %.4f ms %5.0f W %.3f J | inv(alt = plain loads) %.4f ms %5.0f W %.3f J" % (
+                    G, names[flags], f["ms_per_launch"], f.get("watts_mean", 0), f["joules_per_launch_above_sleep"],
+                    i["ms_per_launch"], i.get("watts_mean", 0), i["joules_per_launch_above_sleep"]), flush=True)
+        res["memflavour"] = mf
         del Xb, fb, yb, xb
 
     if "energy" in sections:

@@ -18,7 +18,8 @@ namespace {
 
 constexpr int F = 513;
 
-template <int FEAT>
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <int FEAT, int NT, int WIDE>
 __device__ __forceinline__ void fwd_run(const float* __restrict__ x, float2* __restrict__ out, float* __restrict__ feat,
                                         long long f0, long long f1, int lane) {
   vf2 raw[8];
@@ -38,9 +39,21 @@ __device__ __forceinline__ void fwd_run(const float* __restrict__ x, float2* __r
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = raw[m] * (vf2){1.0001f, 0.9999f};
     // the row as whole 512-byte aligned blocks of the contiguous (frames, 513) complex stream
-    const long long b0 = (f * F) >> 6, b1 = ((f + 1) * F) >> 6;
-    int m = 0;
-    for (long long blk = b0; blk < b1; ++blk, ++m) __builtin_nontemporal_store(v[m & 7], base + blk * 64 + lane);
+    if (WIDE) {      // 1-KB blocks, 16 bytes per lane
+      const long long b0 = (f * F) >> 7, b1 = ((f + 1) * F) >> 7;
+      int m = 0;
+      for (long long blk = b0; blk < b1; ++blk, ++m) {
+        const vf4 q = {v[(2 * m) & 7].x, v[(2 * m) & 7].y, v[(2 * m + 1) & 7].x, v[(2 * m + 1) & 7].y};
+        vf4* dst = reinterpret_cast<vf4*>(out) + blk * 64 + lane;
+        if (NT) __builtin_nontemporal_store(q, dst); else *dst = q;
+      }
+    } else {
+      const long long b0 = (f * F) >> 6, b1 = ((f + 1) * F) >> 6;
+      int m = 0;
+      for (long long blk = b0; blk < b1; ++blk, ++m) {
+        if (NT) __builtin_nontemporal_store(v[m & 7], base + blk * 64 + lane); else base[blk * 64 + lane] = v[m & 7];
+      }
+    }
     if (FEAT) {
       vf2* fd = reinterpret_cast<vf2*>(feat + f * 128);
       fd[lane] = v[0] + v[1];
@@ -48,6 +61,7 @@ __device__ __forceinline__ void fwd_run(const float* __restrict__ x, float2* __r
   }
 }
 
+template <int NT, int NTLOAD>
 __device__ __forceinline__ void inv_run(const float2* __restrict__ in, float* __restrict__ audio, long long f0, long long f1,
                                         int lane) {
   vf2 acc[6];
@@ -57,7 +71,7 @@ __device__ __forceinline__ void inv_run(const float2* __restrict__ in, float* __
     const vf2* src = reinterpret_cast<const vf2*>(in + f * F);
     vf2 v[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = __builtin_nontemporal_load(&src[lane + 64 * m]);
+    for (int m = 0; m < 8; ++m) v[m] = NTLOAD ? __builtin_nontemporal_load(&src[lane + 64 * m]) : src[lane + 64 * m];
     const float ny = reinterpret_cast<const float*>(src + 512)[0];
     vf2 o0 = acc[0] + v[0] + (vf2){ny, ny}, o1 = acc[1] + v[1];
 #pragma unroll
@@ -65,13 +79,18 @@ __device__ __forceinline__ void inv_run(const float2* __restrict__ in, float* __
     acc[4] = v[6];
     acc[5] = v[7];
     vf2* dst = reinterpret_cast<vf2*>(audio + f * 256);
-    __builtin_nontemporal_store(o0, &dst[lane]);
-    __builtin_nontemporal_store(o1, &dst[lane + 64]);
+    if (NT) {
+      __builtin_nontemporal_store(o0, &dst[lane]);
+      __builtin_nontemporal_store(o1, &dst[lane + 64]);
+    } else {
+      dst[lane] = o0;
+      dst[lane + 64] = o1;
+    }
   }
 }
 
-// KIND 0 forward, 1 forward + 128 features, 2 inverse
-template <int KIND>
+// KIND 0 forward, 1 forward + 128 features, 2 inverse; NT: non-temporal stores; ALT: 16-byte stores (forward) / plain loads (inverse)
+template <int KIND, int NT, int ALT>
 __global__ __launch_bounds__(512) void pat_k(const float* __restrict__ x, const float2* __restrict__ spec_in,
                                              float2* __restrict__ out, float* __restrict__ audio, float* __restrict__ feat,
                                              long long total, long long G) {
@@ -83,8 +102,8 @@ __global__ __launch_bounds__(512) void pat_k(const float* __restrict__ x, const 
   const long long f0 = w * G;
   long long f1 = f0 + G;
   if (f1 > total) f1 = total;
-  if (KIND == 2) inv_run(spec_in, audio, f0, f1, lane);
-  else fwd_run<KIND == 1>(x, out, feat, f0, f1, lane);
+  if (KIND == 2) inv_run<NT, !ALT>(spec_in, audio, f0, f1, lane);
+  else fwd_run<KIND == 1, NT, ALT>(x, out, feat, f0, f1, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- instruction energy
@@ -150,32 +169,49 @@ __global__ __launch_bounds__(256) void ek_k(int iters, float* __restrict__ sink)
   if (acc == 12345.678f) sink[0] = acc;
 }
 
+// flags: bit 0 = plain (temporal) stores instead of non-temporal; bit 1 = 16-byte stores (forward) / plain loads (inverse)
+template <int KIND>
+static void (*pick(int flags))(const float*, const float2*, float2*, float*, float*, long long, long long) {
+  switch (flags & 3) {
+    case 0: return pat_k<KIND, 1, 0>;
+    case 1: return pat_k<KIND, 0, 0>;
+    case 2: return pat_k<KIND, 1, 1>;
+    default: return pat_k<KIND, 0, 1>;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+// flags: bit 0 = plain (temporal) stores instead of non-temporal; bit 1 = 16-byte stores (forward) / plain loads (inverse)
 
-int pat_fwd(const float* x, void* out, float* feat, long long total_frames, int G, int wpb, void* stream) {
+int pat_fwd_flags(const float* x, void* out, float* feat, long long total_frames, int G, int wpb, int flags, void* stream) {
   if (G < 1 || wpb < 1 || wpb > 8) return -1;
   const long long nruns = (total_frames + G - 1) / G;
   const long long blocks = (nruns + wpb - 1) / wpb;
   if (blocks <= 0 || blocks >= (1LL << 31)) return -1;
-  if (feat)
-    hipLaunchKernelGGL(pat_k<1>, dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, x, nullptr, (float2*)out,
-                       nullptr, feat, total_frames, (long long)G);
-  else
-    hipLaunchKernelGGL(pat_k<0>, dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, x, nullptr, (float2*)out,
-                       nullptr, nullptr, total_frames, (long long)G);
+  auto k = feat ? pick<1>(flags) : pick<0>(flags);
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, x, (const float2*)nullptr, (float2*)out,
+                     (float*)nullptr, feat, total_frames, (long long)G);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-int pat_inv(const void* spec, float* audio, long long total_frames, int G, int wpb, void* stream) {
+int pat_inv_flags(const void* spec, float* audio, long long total_frames, int G, int wpb, int flags, void* stream) {
   if (G < 1 || wpb < 1 || wpb > 8) return -1;
   const long long nruns = (total_frames + G - 1) / G;
   const long long blocks = (nruns + wpb - 1) / wpb;
   if (blocks <= 0 || blocks >= (1LL << 31)) return -1;
-  hipLaunchKernelGGL(pat_k<2>, dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, nullptr, (const float2*)spec,
-                     nullptr, audio, nullptr, total_frames, (long long)G);
+  hipLaunchKernelGGL(pick<2>(flags), dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, (const float*)nullptr,
+                     (const float2*)spec, (float2*)nullptr, audio, (float*)nullptr, total_frames, (long long)G);
   return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int pat_fwd(const float* x, void* out, float* feat, long long total_frames, int G, int wpb, void* stream) {
+  return pat_fwd_flags(x, out, feat, total_frames, G, wpb, 0, stream);
+}
+
+int pat_inv(const void* spec, float* audio, long long total_frames, int G, int wpb, void* stream) {
+  return pat_inv_flags(spec, audio, total_frames, G, wpb, 0, stream);
 }
 
 // `blocks` workgroups of four waves; every wave issues iters x 64 instructions of `kind` (EK_SLEEP: iters x 8 s_sleep 16)
