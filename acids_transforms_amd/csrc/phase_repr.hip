@@ -355,7 +355,6 @@ __device__ __forceinline__ void put_phase(const IntParams& p, long long idx, flo
 // NC: columns per thread, as in phase_scan_kernel (NC > 1: one block per clip; forward / backward only)
 template <int METHOD, bool NORM, bool POLAR, int NC>   // SCAN_IF_*; `rescale` = 0 gives the bare fint_* of utils/misc.py
 __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_integrate_kernel(IntParams p, int rescale) {
-  static_assert(NC == 1 || METHOD != SCAN_IF_CENTRAL, "fint_central walks one column per thread");
   const long long T = p.T, F = p.F;
   long long b, fk[NC];
   bool on[NC];
@@ -433,6 +432,126 @@ __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_integrate_kernel(In
         const long long row = FWD ? s : T - 1 - s;
         step(k, s, src_row0[row * ldy + fk[k]], mag_at<POLAR>(p, out_row0 + row * F + fk[k]));
       }
+  } else if constexpr (NC > 1) {
+    // fint_central (utils/misc.py:96-104) in the clip-per-block layout (round 5): the same statements as the one-column
+    // form below, NC columns per thread, the block's wavefronts in lockstep so that whole rows leave together (what
+    // made the forward / backward scans 1.5x faster at F = 513, see phase_scan_kernel).
+    const float* src_row0 = p.y + b * T * ldy;
+    const long long out_row0 = b * T * F;
+    auto zk = [&](int k, long long t) { return prep(t, src_row0[t * ldy + fk[k]]); };
+    auto putk = [&](int k, long long row, float ph) {
+      if (on[k]) p.out[out_row0 + row * F + fk[k]] = ph;
+    };
+    constexpr int RA = kRowsAhead / 2;        // rows ahead per chain (two chains at even T)
+    if (T == 1) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) putk(k, 0, zk(k, 0));
+      return;
+    }
+    float even[NC], cur[NC];
+    if ((T & 1) == 0) {
+      // even T: two independent chains (even rows upwards from row 0, odd rows downwards from row T-1), walked together
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        even[k] = zk(k, 0);
+        cur[k] = zk(k, T - 1);
+        putk(k, 0, even[k]);
+      }
+      const long long J = T / 2 - 1;
+      long long j = 0;
+      for (; j + RA <= J; j += RA) {
+        float ve[NC][RA], vo[NC][RA];
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+          for (int r = 0; r < RA; ++r) {
+            const long long je = 2 * (j + r + 1), io = T - 1 - 2 * (j + r);
+            ve[k][r] = src_row0[(je - 1) * ldy + fk[k]];
+            vo[k][r] = src_row0[(io - 1) * ldy + fk[k]];
+          }
+#pragma unroll
+        for (int r = 0; r < RA; ++r)
+#pragma unroll
+          for (int k = 0; k < NC; ++k) {
+            const long long je = 2 * (j + r + 1), io = T - 1 - 2 * (j + r);
+            even[k] = even[k] + 4.0f * prep(je - 1, ve[k][r]);
+            putk(k, je, even[k]);
+            cur[k] = cur[k] - 4.0f * prep(io - 1, vo[k][r]);
+            putk(k, io - 2, cur[k]);
+          }
+        __syncthreads();
+      }
+      for (; j < J; ++j)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const long long je = 2 * (j + 1), io = T - 1 - 2 * j;
+          even[k] = even[k] + 4.0f * zk(k, je - 1);
+          putk(k, je, even[k]);
+          cur[k] = cur[k] - 4.0f * zk(k, io - 1);
+          putk(k, io - 2, cur[k]);
+        }
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        cur[k] = cur[k] - 4.0f * zk(k, 0);      // i = 1: out[-1]
+        putk(k, T - 1, cur[k]);
+      }
+      return;
+    }
+    // odd T: the second loop starts from the first chain's LAST value and rewrites every even row the first one wrote
+    // (out[i-2] = out[i] - 4 x[i-1], i = T-1 ... 2), the odd rows stay 0.  So the first chain is walked for its last value
+    // only -- its stores would all be overwritten -- and every row is written once.
+#pragma unroll
+    for (int k = 0; k < NC; ++k) even[k] = zk(k, 0);
+    {
+      long long i = 2;
+      for (; i + 2 * (kRowsAhead - 1) < T; i += 2 * kRowsAhead) {
+        float v[NC][kRowsAhead];
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+          for (int r = 0; r < kRowsAhead; ++r) v[k][r] = src_row0[(i + 2 * r - 1) * ldy + fk[k]];
+#pragma unroll
+        for (int r = 0; r < kRowsAhead; ++r)
+#pragma unroll
+          for (int k = 0; k < NC; ++k) even[k] = even[k] + 4.0f * prep(i + 2 * r - 1, v[k][r]);
+        __syncthreads();
+      }
+      for (; i < T; i += 2)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) even[k] = even[k] + 4.0f * zk(k, i - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      cur[k] = even[k];
+      putk(k, T - 1, cur[k]);
+    }
+    {
+      long long i = T - 1;
+      for (; i - 2 * (kRowsAhead - 1) >= 2; i -= 2 * kRowsAhead) {
+        float v[NC][kRowsAhead];
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+          for (int r = 0; r < kRowsAhead; ++r) v[k][r] = src_row0[(i - 2 * r - 1) * ldy + fk[k]];
+#pragma unroll
+        for (int r = 0; r < kRowsAhead; ++r)
+#pragma unroll
+          for (int k = 0; k < NC; ++k) {
+            const long long ii = i - 2 * r;
+            cur[k] = cur[k] - 4.0f * prep(ii - 1, v[k][r]);
+            putk(k, ii - 2, cur[k]);
+            putk(k, ii - 1, 0.0f);
+          }
+        __syncthreads();
+      }
+      for (; i >= 2; i -= 2)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          cur[k] = cur[k] - 4.0f * zk(k, i - 1);
+          putk(k, i - 2, cur[k]);
+          putk(k, i - 1, 0.0f);
+        }
+    }
   } else {
     // fint_central (utils/misc.py:96-104), statement by statement.  Rows the reference never writes stay 0.
     auto z = [&](long long t) { return prep(t, src[t * ldy]); };
@@ -637,7 +756,7 @@ static int phase_integrate_impl(const float* y, int64_t ld_y, int64_t B, int64_t
   void (*kernel)(IntParams, int) = nullptr;
   // the complex-output form (mag * exp(i phase): sincos and a second input per element) is slower in the clip-per-block
   // layout (PolarIF.invert 2.30 -> 3.29 ms): it stays on flattened columns
-  const int nc = (method == SCAN_IF_CENTRAL || POLAR) ? 0 : clip_block_columns(F, B, 4);
+  const int nc = POLAR ? 0 : clip_block_columns(F, B, 4);
   dim3 g = grid, blk = block;
   if (nc) {
     g = dim3((unsigned)B);
@@ -651,6 +770,10 @@ static int phase_integrate_impl(const float* y, int64_t ld_y, int64_t B, int64_t
     kernel = norm ? phase_integrate_kernel<SCAN_IF_BACKWARD, true, POLAR, 2> : phase_integrate_kernel<SCAN_IF_BACKWARD, false, POLAR, 2>;
   else if (method == SCAN_IF_BACKWARD && nc == 4)
     kernel = norm ? phase_integrate_kernel<SCAN_IF_BACKWARD, true, POLAR, 4> : phase_integrate_kernel<SCAN_IF_BACKWARD, false, POLAR, 4>;
+  else if (method == SCAN_IF_CENTRAL && nc == 2)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_CENTRAL, true, false, 2> : phase_integrate_kernel<SCAN_IF_CENTRAL, false, false, 2>;
+  else if (method == SCAN_IF_CENTRAL && nc == 4)
+    kernel = norm ? phase_integrate_kernel<SCAN_IF_CENTRAL, true, false, 4> : phase_integrate_kernel<SCAN_IF_CENTRAL, false, false, 4>;
   else if (method == SCAN_IF_FORWARD)
     kernel = norm ? phase_integrate_kernel<SCAN_IF_FORWARD, true, POLAR, 1> : phase_integrate_kernel<SCAN_IF_FORWARD, false, POLAR, 1>;
   else if (method == SCAN_IF_BACKWARD)

@@ -143,6 +143,7 @@ def dry_plan(args):
                     "unless WORLD_SIZE is already set (torch.distributed.run), in which case the launcher's ranks are used" % (n, n - 1),
         "backend": "nccl (RCCL over xGMI), init_process_group(device_id=cuda:LOCAL_RANK, timeout=%d s)" % dist_timeout_s(),
         "timeout_s": dist_timeout_s(),
+        "environment": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0 (default set by the ranks)")},
         "rank_to_device": {str(r): "cuda:%d" % r for r in range(n)},
         "scaling": "weak: %d clips x 4 s per GPU, %d clips in all" % (B, n * B),
         "clip_ranges": {str(r): [r * B, (r + 1) * B] for r in range(n)},
@@ -188,8 +189,6 @@ def launch_ranks(args) -> int:
     port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
     procs = []
     for r in range(n):
-        # the children inherit the environment as it is (this image exports HSA_ENABLE_IPC_MODE_LEGACY=0 itself: RCCL's
-        # peer buffers need dmabuf IPC here; it is not for this program to set or unset)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -226,6 +225,13 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
         sys.exit(0)
     if _args.gpus > 1:
         sys.exit(launch_ranks(_args))
+
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # Multi-process GPU work on this pool: the host driver supports dmabuf IPC only, and RCCL's peer buffers (and any
+    # cross-process sharing of device memory) fail with `hipIpcGetMemHandle: invalid argument` unless the HSA runtime is
+    # told so BEFORE it initialises.  The image exports this already; a default only (never overrides the caller), set
+    # here so that a rank started by any launcher has it before torch loads the runtime.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -398,6 +398,42 @@ def main():
         res["pattern"] = pat
         del Xb, fb, yb, xb
 
+    if "phase" in sections:
+        # the phase side with time, watts and clock: which of these kernels sit on the power cap too
+        ph = {}
+        Xs = stft(x)
+        x_odd = x[:, :CLIP - HOP].contiguous()                  # T = 689: fint_central's odd-T form
+        Xo = stft(x_odd)
+        inst = ops.phase_scan(Xs, "forward")
+        insto = ops.phase_scan(Xo, "forward")
+        pol = A.Polar().to(dev)
+        pol.scale_data(Xs[:8])
+        comp = stft + pol
+        pif = A.PolarIF().to(dev)
+        pif.scale_data(Xs[:8])
+        Yp, Yi = pol(Xs), pif(Xs)
+        cases = [
+            ("if_forward (scan)", lambda: ops.phase_scan(Xs, "forward"), 12 * 513, T),
+            ("if_central (scan)", lambda: ops.phase_scan(Xs, "central"), 12 * 513, T),
+            ("if_invert forward T=690", lambda: ops.phase_integrate(inst, "forward"), 8 * 513, T),
+            ("if_invert central T=690", lambda: ops.phase_integrate(inst, "central"), 8 * 513, T),
+            ("if_invert central T=689", lambda: ops.phase_integrate(insto, "central"), 8 * 513, T - 1),
+            ("if_invert backward T=690", lambda: ops.phase_integrate(inst, "backward"), 8 * 513, T),
+            ("Polar.forward", lambda: pol(Xs), 16 * 513, T),
+            ("Polar.invert", lambda: pol.invert(Yp), 16 * 513, T),
+            ("STFT+Polar one kernel", lambda: comp(x), 1024 + 8 * 513, T),
+            ("PolarIF.forward", lambda: pif(Xs), 16 * 513, T),
+            ("PolarIF.invert", lambda: pif.invert(Yi), 16 * 513, T),
+        ]
+        for name, fn, bpf, tt in cases:
+            w = powered_loop(fn, seconds=1.0, chunk=10, warm=10)
+            w["frac_of_8TBps"] = B * tt * bpf / (w["ms_per_launch"] * 1e-3) / 8e12
+            ph[name] = w
+            print("phase  %-26s %.4f ms  %.3f of 8 TB/s  %5.0f W  sclk %4.0f MHz" % (
+                name, w["ms_per_launch"], w["frac_of_8TBps"], w.get("watts_mean", 0), w.get("sclk_mean", 0)), flush=True)
+        res["phase"] = ph
+        del Xs, Xo, inst, insto, Yp, Yi, x_odd
+
     if "memflavour" in sections:
         # Joules of the step's memory streams by store / load flavour (under a power cap the cheapest stream wins, not the
         # fastest one at full clock): non-temporal vs plain stores, 8- vs 16-byte stores, non-temporal vs plain loads
