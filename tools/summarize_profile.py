@@ -74,7 +74,9 @@ if traffic:
     bt = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `%s`; FETCH_SIZE "
                       "doubled per MI355X_MICROARCH.md (gfx950)" % tag}
     for key, needle in (("stft_fwd", "stft1024_h256_fwd_kernel<false, 1, 8, true, 0, false, 2, 2, 8, 2"), ("stft_fwd_unfused", "stft1024_h256_fwd_kernel<false, 0"),
-                        ("istft", "istft1024_ola_kernel"), ("mel", "mel_banded_kernel")):
+                        ("istft", "istft1024_tile_kernel"), ("istft", "istft1024_ola_kernel"), ("mel", "mel_banded_kernel")):
+        if key in bt:
+            continue
         for k, v in js.items():
             if needle in k:
                 bt[key] = int(round(v["read_bytes_corrected"] + v["write_bytes"], -5))
