@@ -1503,7 +1503,19 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
     // is the heap's.  That is checked as the group runs (in rank order); a collision abandons the fast path and the
     // frame is redone on the heap.  (tools/fuzz_rt_ties.py: injected ties, bit for bit against the heap kernel.)
     bool fast_done = false;
-    if (p.ranks != nullptr && max_val > abstol) {
+    bool try_fast = p.ranks != nullptr && max_val > abstol;
+    if (try_fast) {
+      // Pervasive ties: a held frame, a hop-periodic tone or a test signal makes row f equal row f-1, every
+      // pop then lands in a tie group whose block visits its tied partner and the frame is redone on the heap anyway --
+      // after paying for the tables, the records and the aborted flood.  The pre-pass has already marked the tied ranks:
+      // when more than a quarter of the 2F candidates are tied the attempt is skipped.
+      const unsigned short* grec0 = p.ranks + ((long long)s * p.n + (f - 2)) * p.rank_stride;
+      int nt = (lane < (2 * F + 31) / 32) ? __popc(reinterpret_cast<const unsigned*>(grec0 + 4 * F)[lane]) : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) nt += __shfl_xor(nt, o, 64);
+      if (2 * nt > F) try_fast = false;
+    }
+    if (try_fast) {
       const unsigned short* grec = p.ranks + ((long long)s * p.n + (f - 2)) * p.rank_stride;
       // LDS: per-rank records where the heap would be (ONE ds_read_b128 per pop), the rank tables and two bitmaps behind
       // them (the launcher sized the allocation for that).  A record is {phase, targets, step up, step down}:

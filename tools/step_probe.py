@@ -398,6 +398,27 @@ def main():
         res["pattern"] = pat
         del Xb, fb, yb, xb
 
+    if "featonly" in sections and "dev" in libs.handles:
+        # the literal configs[1] forward (features only) in its two builds -- three waves per SIMD with twiddles and window in
+        # registers (product) against four waves per SIMD reading them from LDS (dev switch ACIDS_FWD_NOHYB): time, watts, clock.
+        # If both sit at the cap, more latency hiding cannot buy time, only fewer Joules can.
+        off, sc = mag._affine()
+        fo = {}
+        call = lambda: ops.stft_mel_forward(x, stft.window[:N_FFT], mag._banded(), "log1p", off, sc, mag._eps, want_spectrum=False)  # noqa: E731
+        libs.use("dev")
+        for rnd in range(3):
+            for name, env in (("3 waves/SIMD, registers", None), ("4 waves/SIMD, LDS tables", "1")):
+                if env:
+                    os.environ["ACIDS_FWD_NOHYB"] = env
+                w = powered_loop(call, seconds=1.0, chunk=20, warm=30)
+                os.environ.pop("ACIDS_FWD_NOHYB", None)
+                w["microjoules_per_frame"] = w.get("watts_mean", 0) * w["ms_per_launch"] * 1e-3 / frames * 1e6
+                fo.setdefault(name, []).append(w)
+                print("featonly round %d %-26s %.4f ms %5.0f W sclk %4.0f MHz  %.3f uJ/frame" % (
+                    rnd, name, w["ms_per_launch"], w.get("watts_mean", 0), w.get("sclk_mean", 0), w["microjoules_per_frame"]), flush=True)
+        libs.use("0")
+        res["featonly"] = fo
+
     if "phase" in sections:
         # the phase side with time, watts and clock: which of these kernels sit on the power cap too
         ph = {}
