@@ -29,7 +29,11 @@ for F in (513, 512, 576):
     t1 = timeit(lambda: ops.phase_integrate(y, "forward"))
     t2 = timeit(lambda: ops.phase_scan(X, "forward"))
     t3 = timeit(lambda: ops.phase_scan(X, "angle"))
+    t4 = timeit(lambda: ops.phase_integrate(y, "central"))
+    t5 = timeit(lambda: ops.phase_integrate(y[:, :T - 1].contiguous() if False else y_odd, "central")) if (y_odd := y[:, :T - 1].contiguous()) is not None else 0
     print("F=%d  IF.invert forward %.3f ms (%.2f TB/s)   IF forward %.3f ms (%.2f TB/s)   angle %.3f ms (%.2f TB/s)" % (
         F, t1, B * T * F * 8 / t1 / 1e9, t2, B * T * F * 12 / t2 / 1e9, t3, B * T * F * 12 / t3 / 1e9), flush=True)
-    del y, X
+    print("F=%d  IF.invert central even T %.3f ms (%.2f TB/s)   odd T %.3f ms (%.2f TB/s)" % (
+        F, t4, B * T * F * 8 / t4 / 1e9, t5, B * (T - 1) * F * 8 / t5 / 1e9), flush=True)
+    del y, X, y_odd
 
