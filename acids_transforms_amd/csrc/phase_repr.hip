@@ -595,49 +595,44 @@ __global__ __launch_bounds__(NC > 1 ? 1024 : 256) void phase_integrate_kernel(In
       put(T - 1, cur);
       return;
     }
-    float even = z(0);                       // out[0]
-    put(0, even);
+    // Odd T (even T returned above): the second loop starts from the first chain's LAST value and rewrites every even
+    // row the first one wrote (out[i-2] = out[i] - 4 x[i-1], i = T-1 ... 2); the odd rows stay 0.  The first chain is
+    // therefore walked for its last value only (its stores were all dead) and every row is written once, odd rows with
+    // their even neighbours.
+    float even = z(0);
     long long i = 2;
     for (; i + 2 * (kRowsAhead - 1) < T; i += 2 * kRowsAhead) {   // out[i] = out[i-2] + 4 x[i-1]
-      float v[kRowsAhead], m[kRowsAhead];
+      float v[kRowsAhead];
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) {
-        v[k] = src[(i + 2 * k - 1) * ldy];
-        m[k] = mag_at<POLAR>(p, base + (i + 2 * k) * F);
-      }
+      for (int k = 0; k < kRowsAhead; ++k) v[k] = src[(i + 2 * k - 1) * ldy];
 #pragma unroll
-      for (int k = 0; k < kRowsAhead; ++k) {
-        even = even + 4.0f * prep(i + 2 * k - 1, v[k]);
-        put_phase<POLAR>(p, base + (i + 2 * k) * F, even, m[k]);
-      }
+      for (int k = 0; k < kRowsAhead; ++k) even = even + 4.0f * prep(i + 2 * k - 1, v[k]);
     }
-    for (; i < T; i += 2) {
-      even = even + 4.0f * z(i - 1);
-      put(i, even);
-    }
-    for (long long j = 1; j < T; j += 2) put(j, 0.0f);
-    // out[T-1]: x[T-1] when T is even (the forward chain only touched even rows), else the chain's last value
-    float cur = ((T - 1) & 1) ? z(T - 1) : even;
+    for (; i < T; i += 2) even = even + 4.0f * z(i - 1);
+    float cur = even;
     put(T - 1, cur);
     i = T - 1;
-    for (; i - 2 * (kRowsAhead - 1) >= 1; i -= 2 * kRowsAhead) {   // out[i-2] = out[i] - 4 x[i-1]; i = 1 writes row "-1"
-      float v[kRowsAhead], m[kRowsAhead];
+    for (; i - 2 * (kRowsAhead - 1) >= 2; i -= 2 * kRowsAhead) {   // out[i-2] = out[i] - 4 x[i-1]
+      float v[kRowsAhead], m[kRowsAhead], mz[kRowsAhead];
 #pragma unroll
       for (int k = 0; k < kRowsAhead; ++k) {
         const long long ii = i - 2 * k;
         v[k] = src[(ii - 1) * ldy];
-        m[k] = mag_at<POLAR>(p, base + ((ii - 2 >= 0) ? ii - 2 : T - 1) * F);
+        m[k] = mag_at<POLAR>(p, base + (ii - 2) * F);
+        mz[k] = mag_at<POLAR>(p, base + (ii - 1) * F);
       }
 #pragma unroll
       for (int k = 0; k < kRowsAhead; ++k) {
         const long long ii = i - 2 * k;
         cur = cur - 4.0f * prep(ii - 1, v[k]);
-        put_phase<POLAR>(p, base + ((ii - 2 >= 0) ? ii - 2 : T - 1) * F, cur, m[k]);
+        put_phase<POLAR>(p, base + (ii - 2) * F, cur, m[k]);
+        put_phase<POLAR>(p, base + (ii - 1) * F, 0.0f, mz[k]);
       }
     }
-    for (; i >= 1; i -= 2) {
+    for (; i >= 2; i -= 2) {
       cur = cur - 4.0f * z(i - 1);
-      put((i - 2 >= 0) ? i - 2 : T - 1, cur);
+      put(i - 2, cur);
+      put(i - 1, 0.0f);
     }
   }
 }

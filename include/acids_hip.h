@@ -131,7 +131,10 @@ size_t at_istft_workspace_bytes(int64_t B, int64_t T, int n_fft, int hop);
  * required for n_fft = 1024, 512, 2048 and 4096 with hop = n_fft/8, n_fft/4 or n_fft/2 -- the fused kernels, for which
  * at_istft_workspace_bytes is 0 -- and may be NULL otherwise.  n_fft = 128, 256, 512, 2048 and 4096 run on the
  * register FFT core (stft_small.hip, stft512.hip, stft2048.hip, stft4096.hip), the other powers of two on the generic
- * LDS kernel. */
+ * LDS kernel.  n_fft = 1024, hop = 256: a batch with at least two tiles of ~175 frames for every workgroup the chip
+ * holds runs as workgroup tiles (the overlap state crosses the cuts between a workgroup's waves through LDS), anything
+ * smaller as one run per wave; the window is taken inside the accumulation (fma, frame order) in both, so a clip's bits
+ * do not depend on the batch it rides in (AT_VARIANT_ISTFT_RUNS = 1 forces the long runs). */
 int at_istft(const float *X_complex, const float *mag, const float *phase, int64_t B, int64_t T, int n_fft, int hop,
              const float *inv_window, const float *env16, float *y, void *workspace, size_t workspace_bytes,
              void *stream);
