@@ -240,6 +240,25 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float2* lds = lds_all + wave * kWaveLds + kFeatCarry;
   float2* tab = lds_all + FWD_WAVES * kWaveLds;
+  // (non-persistent launches) the eight segments of this wave's first frame are requested BEFORE the workgroup stages its
+  // LDS tables: their latency (cold HBM) then runs under the table fill and the barrier instead of after them -- part of
+  // what a run start costs (profiles/r04_launch_shape.md (c)), and what short runs in dispatch order have to pay per run
+  float2 raw_first[8];
+  auto load_first_frame = [&](const long long run, float2 (&raw)[8]) {
+    const long long b = run / p.runs_per_clip;
+    if (b >= p.B) return;
+    const long long t0 = (run - b * p.runs_per_clip) * p.frames_per_run;
+    if (t0 >= p.T) return;
+    const float* clip = p.x + b * p.clip_stride;
+    const bool clip_aligned = ((((uintptr_t)clip) & 7) == 0);
+    const long long s0 = t0 * (128 * HS) - 512;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const long long i0 = s0 + 128 * m;
+      raw[m] = load_pair(clip, p.L, i0, i0 >= 0 && i0 + 128 <= p.L, clip_aligned, 2 * lane);
+    }
+  };
+  if constexpr (!PW) load_first_frame((long long)blockIdx.x * FWD_WAVES + wave, raw_first);
   // workgroup-shared constants: (twiddle table,) analysis window, band weights
   if (TWLDS)
     for (int i = threadIdx.x; i < kTwiddleCount; i += 64 * FWD_WAVES) tab[i] = twiddle_for_lds<false>(p.tw, i);
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   const long long L = p.L;
   const int lane2 = 2 * lane;
 
-  auto do_run = [&](const long long run) {
+  auto do_run = [&](const long long run, const bool preloaded) {
   const long long b = run / p.runs_per_clip;
   if (b >= p.B) return;
   const long long r = run - b * p.runs_per_clip;
@@ -333,15 +352,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   const float* clip = p.x + b * p.clip_stride;
   const bool clip_aligned = ((((uintptr_t)clip) & 7) == 0);  // frame starts are multiples of 256 samples
 
-  // first frame of the run: all eight segments
+  // first frame of the run: all eight segments (already requested above unless the workgroup is persistent)
   float2 raw[8];
-  {
-    const long long s0 = t0 * H - 512;
+  if (preloaded) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const long long i0 = s0 + 128 * m;
-      raw[m] = load_pair(clip, L, i0, i0 >= 0 && i0 + 128 <= L, clip_aligned, lane2);
-    }
+    for (int m = 0; m < 8; ++m) raw[m] = raw_first[m];
+  } else {
+    load_first_frame(run, raw);
   }
   // Make the prologue loads architecturally complete here: otherwise the loop-top wait is the merge of
   // "just loaded" (from this prologue) and "loaded nine stores ago" (from the back edge) and collapses to
@@ -722,7 +739,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   // compiler's vmcnt accounting lets the stores stay in flight across iterations.
   long long t = t0;
   long long t_fast_end = (L >= 512) ? (L - 512) / H : 0;         // first t whose successor needs reflection
-  if (t_fast_end > t1 - 1) t_fast_end = t1 - 1;        // the last frame of the run has no successor to fetch
+  // The last frame of a run whose successor (another run's first frame) lies inside the clip fetches that frame's new
+  // samples like any other and drops them: 1 KB read again by the neighbour (L2), against a trip through the generic loop
+  // below -- per run, which is what makes short runs expensive.  Only the clip's last frames take the generic loop.
+  if (t_fast_end > t1) t_fast_end = t1;
   if (!clip_aligned) t_fast_end = t0;                  // odd-length clips: generic loop only
   if (t < t_fast_end) {
     // segment 8 - HS of frame t+1 starts at original sample H (t+1) - 512 + 128 (8 - HS) = H t + 512
@@ -767,14 +787,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (TWLDS && !CMBUF && !HYB) ? 4 : 3) 
   };   // do_run
 
   if constexpr (!PW) {
-    do_run((long long)blockIdx.x * FWD_WAVES + wave);
+    do_run((long long)blockIdx.x * FWD_WAVES + wave, true);
   } else {
     for (int it = 0;; ++it) {
       const unsigned tile = __builtin_amdgcn_readfirstlane(s_tile[it & 1]);
       if (tile >= p.n_tiles) break;
       unsigned nxt = 0;
       if (threadIdx.x == 0) nxt = atomicAdd(p.tile_ctr, 1u);       // consumed after this tile's run
-      do_run((long long)tile * FWD_WAVES + wave);
+      do_run((long long)tile * FWD_WAVES + wave, false);
       if (threadIdx.x == 0) s_tile[(it + 1) & 1] = nxt;
       __syncthreads();
     }
