@@ -112,7 +112,7 @@ extern "C" {
 int at_abi_version(void) { return 4; }
 
 int at_set_variant(int which, int value) {
-  if (which < 0 || which >= kVarCount || value < 0 || value > 3) return AT_EINVAL;
+  if (which < 0 || which >= kVarCount || value < 0 || value > 4) return AT_EINVAL;
   g_variants[which].store(value, std::memory_order_relaxed);
   return AT_OK;
 }

@@ -1078,6 +1078,7 @@ struct RtParams {
   // rank: "same magnitude as the rank before".  Null: heap path only.
   unsigned short* ranks;
   long long rank_stride;    // u16 elements per (stream, frame) record
+  int scan_path;            // 1: try the wavefront-parallel closure (rt_scan_frame) before the rank / heap floods
 };
 
 // one record: u16 ent_of_rank[2F], u16 rank_of_ent[2F], u32 same_as_previous[ceil(2F / 32)] (bit r: the magnitude at rank r
@@ -1374,6 +1375,202 @@ __global__ __launch_bounds__(64) void pghi_hgi_rt_lds_kernel(RtParams p) {
   }
 }
 
+#ifdef AT_DEV_SWITCHES
+__device__ unsigned g_rt_stats[8];     // dev builds: frames, scan successes, resolution rounds, declined: reseed / tie
+#define RT_STAT(i, v) do { if (lane == 0) atomicAdd(&g_rt_stats[i], (unsigned)(v)); } while (0)
+#else
+#define RT_STAT(i, v) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Realtime flood of ONE frame without a queue (round 5): the wavefront-parallel closure.
+//
+// The frame's flood (dgt.py:413-465) runs on a two-row strip: every live bin of row f-1 is a SOURCE in the heap from the
+// start (key a_k = its magnitude, phase known), row f is unvisited (key b_k); a popped source (f-1, k) visits (f, k), a
+// popped (f, k) visits (f, k+1) and -- unless that would be bin 0 (:453) -- (f, k-1); "visit" = take the phase from the
+// popping entry, push, mark.  With DISTINCT keys the order of pops does not depend on the queue, and neither does the
+// one thing the phases depend on: WHICH neighbour reaches a bin first.  An entry pops at the level
+//     lev(e) = min(key(e), level at which e was pushed)        (the running minimum of the popped keys when e leaves)
+// and entries leave in order of decreasing level, so bin k is visited at R(k) = max(a_k, lev(f, k-1), lev(f, k+1)) by
+// whichever of the three attains the maximum, and lev(f, k) = min(b_k, R(k)).  On a path graph the closure is two
+// directional scans of clamp functions x -> min(b_k, max(a_k, x)) (a composition of clamps is a clamp: a parallel prefix
+// over the lanes), and the phases follow the parent pointers: chains along the row, each bin ONE float addition onto its
+// parent's final phase -- the same additions as the heap flood, so the same bits.
+//
+// The unmarked seed (:427: the frame maximum is pushed first and NOT marked visited) is an extra entry S at bin kmax that
+// pops at level b_kmax whatever happens to the bin itself, and hands its neighbours the phase the bin holds AT THAT TIME:
+// the visited one if the bin's own source is larger than b_kmax, the initial one otherwise (the bin is then visited
+// later, possibly by one of S's own children).
+//
+// Declined (returns false, nothing written; the caller runs the rank / heap flood): a live bin nothing reaches (the
+// reference reseeds, :461-465 -- sparse spectra), or two candidates for a bin's parent with EQUAL levels (tied
+// magnitudes that actually compete: only the heap knows their order).  Ties that never meet are harmless.
+__device__ bool rt_scan_frame(const int F, const int lane, const float abstol, const int kmax, const float* srow,
+                              const float* hrow, const float* ph0, float* ph1, const float* tg0, const float* tg1,
+                              const float* fg1, float* scratch) {
+  const float NEG = -__builtin_inff(), POS = __builtin_inff();
+  float* xl = scratch;                                   // level arriving at bin k from the left
+  float* yr = scratch + F;                               // ... from the right
+  int* par = reinterpret_cast<int*>(scratch + 2 * F);    // 0 dead / 1 source / 2 left / 3 right; bit 4: phase final
+  auto sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int C = (F + 63) >> 6;                           // contiguous bins per lane
+  const int k0 = lane * C < F ? lane * C : F;
+  const int k1 = k0 + C < F ? k0 + C : F;
+  // the clamp of bin k: level at which (f, k) pops, given the best level arriving from behind
+  auto clamp_of = [&](int k, float& lo, float& hi) {
+    const float b = srow[k];
+    if (k == kmax) {                       // S pops at its own key
+      lo = hi = b;
+    } else if (!(b > abstol)) {            // dead: never visited, never pops
+      lo = hi = NEG;
+    } else {
+      const float a = hrow[k];
+      hi = b;
+      lo = a > abstol ? fminf(a, b) : NEG;
+    }
+  };
+  auto apply = [](float lo, float hi, float v) { return fminf(hi, fmaxf(lo, v)); };
+
+  // ---- left-to-right: the lane's chunk as one clamp, inclusive scan over the lanes, then the per-bin arrivals
+  float lo = NEG, hi = POS;
+  for (int k = k0; k < k1; ++k) {
+    float l, h;
+    clamp_of(k, l, h);
+    lo = apply(l, h, lo);
+    hi = apply(l, h, hi);
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float plo = __shfl_up(lo, d, 64), phi = __shfl_up(hi, d, 64);
+    if (lane >= d) {
+      const float nlo = apply(lo, hi, plo), nhi = apply(lo, hi, phi);
+      lo = nlo;
+      hi = nhi;
+    }
+  }
+  float arr = __shfl_up(lo, 1, 64);        // everything left of this lane applied to "nothing arrives" = its lower bound
+  if (lane == 0) arr = NEG;
+  for (int k = k0; k < k1; ++k) {
+    xl[k] = arr;
+    float l, h;
+    clamp_of(k, l, h);
+    arr = apply(l, h, arr);
+  }
+  // ---- right-to-left
+  lo = NEG;
+  hi = POS;
+  for (int k = k1 - 1; k >= k0; --k) {
+    float l, h;
+    clamp_of(k, l, h);
+    lo = apply(l, h, lo);
+    hi = apply(l, h, hi);
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float plo = __shfl_down(lo, d, 64), phi = __shfl_down(hi, d, 64);
+    if (lane + d < 64) {
+      const float nlo = apply(lo, hi, plo), nhi = apply(lo, hi, phi);
+      lo = nlo;
+      hi = nhi;
+    }
+  }
+  arr = __shfl_down(lo, 1, 64);
+  if (lane == 63) arr = NEG;
+  for (int k = k1 - 1; k >= k0; --k) {
+    yr[k] = k >= 1 ? arr : NEG;            // bin 0 is never reached downward
+    float l, h;
+    clamp_of(k, l, h);
+    arr = apply(l, h, arr);
+  }
+  sync();
+
+  // ---- parents.  The seed's own bin sees its neighbours as S's children (S reaches them whatever else does).
+  const float bmax = srow[kmax];
+  const float amax = hrow[kmax];
+  const float cmax = amax > abstol ? amax : NEG;
+  bool bad = false, bad_reseed = false;
+  for (int k = k0; k < k1; ++k) {
+    const float b = srow[k];
+    int code = 0;
+    if (b > abstol) {
+      const float a = hrow[k];
+      const float c = a > abstol ? a : NEG;
+      float x = xl[k], y = yr[k];
+      if (k == kmax) {
+        if (k - 1 >= 1 && srow[k - 1] > abstol) x = srow[k - 1];
+        if (k >= 1 && k + 1 < F && srow[k + 1] > abstol) y = srow[k + 1];
+      }
+      const float m = fmaxf(c, fmaxf(x, y));
+      if ((int)(c == m) + (int)(x == m) + (int)(y == m) > 1 && m != NEG) bad = true;  // competing tie
+      // the seed's bin visited at the very level S pops at (its source or a neighbour ties with the frame maximum): which
+      // phase S hands on is then the heap's to say
+      if (k == kmax && m == bmax) bad = true;
+      code = m == NEG ? 4 : (c == m ? 1 : (x == m ? 2 : 3));
+    }
+    par[k] = code;
+  }
+  // Live bins nothing reaches (code 4) are what the reference reseeds (:461-465), largest first.  A reseeded bin keeps
+  // its initial phase and floods its own island of unreached live neighbours; an island of ONE bin -- bin 0 under a dead
+  // source is the usual case: nothing reaches bin 0 from above (:453) -- floods nothing and meets nobody, whatever the
+  // order of the reseeds.  Larger islands are left to the queue.
+  sync();
+  for (int k = k0; k < k1; ++k)
+    if (par[k] == 4 && ((k >= 1 && par[k - 1] == 4) || (k + 1 < F && par[k + 1] == 4))) bad = bad_reseed = true;
+  RT_STAT(0, 1);
+  if (__ballot(bad) != 0) {
+    RT_STAT(__ballot(bad_reseed) != 0 ? 3 : 4, 1);
+    return false;
+  }
+  const float phi_s = cmax > bmax ? ph0[kmax] + 0.5f * (tg0[kmax] + tg1[kmax]) : ph1[kmax];
+  sync();
+
+  // ---- phases along the parent pointers: a left-to-right pass settles sources and chains that lean left, a right-to-
+  // left pass the ones that lean right; chains that cross a lane boundary take another round
+  for (int round = 0; round <= 64; ++round) {
+    bool pending = false;
+    for (int k = k0; k < k1; ++k) {
+      const int code = par[k];
+      if (code == 1) {
+        ph1[k] = ph0[k] + 0.5f * (tg0[k] + tg1[k]);
+        par[k] = 1 | 16;
+      } else if (code == 2) {
+        const int j = k - 1;
+        const bool ready = j == kmax || (par[j] & 16) != 0;
+        if (ready) {
+          const float pp = j == kmax ? phi_s : ph1[j];
+          ph1[k] = pp + 0.5f * (fg1[j] + fg1[k]);
+          par[k] = 2 | 16;
+        } else {
+          pending = true;
+        }
+      }
+    }
+    sync();
+    for (int k = k1 - 1; k >= k0; --k) {
+      if (par[k] == 3) {
+        const int j = k + 1;
+        const bool ready = j == kmax || (par[j] & 16) != 0;
+        if (ready) {
+          const float pp = j == kmax ? phi_s : ph1[j];
+          ph1[k] = pp - 0.5f * (fg1[j] + fg1[k]);
+          par[k] = 3 | 16;
+        } else {
+          pending = true;
+        }
+      }
+    }
+    sync();
+    RT_STAT(2, 1);
+    if (__ballot(pending) == 0) break;
+  }
+  RT_STAT(1, 1);
+  return true;
+}
+
 // Rank pre-pass of the realtime flood.  A frame's flood (dgt.py:413-465) pops, in descending magnitude, entries that are
 // known before it starts: the bins of row f-1 (pushed up front) and the bins of row f (pushed as the flood reaches
 // them).  When no two of those magnitudes are equal, WHICH priority queue hands them out is immaterial -- the pop order
@@ -1472,6 +1669,9 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
 
   for (int f = 2; f < R; ++f) {  // :413
+#ifdef AT_DEV_SWITCHES
+    const unsigned long long tickf0 = wall_clock64();
+#endif
     float max_val = -1.0f;
     long long max_k = F;
     for (int k = lane; k < F; k += 64) {
@@ -1503,7 +1703,17 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
     // is the heap's.  That is checked as the group runs (in rank order); a collision abandons the fast path and the
     // frame is redone on the heap.  (tools/fuzz_rt_ties.py: injected ties, bit for bit against the heap kernel.)
     bool fast_done = false;
-    bool try_fast = p.ranks != nullptr && max_val > abstol;
+    if (p.scan_path && max_val > abstol) {
+#ifdef AT_DEV_SWITCHES
+      const unsigned long long tick0 = wall_clock64();
+#endif
+      fast_done = rt_scan_frame(F, lane, abstol, uni((int)max_k), srow, hrow, ph0, ph1, tg0, tg1, fg1, fg1 + F + (F & 1));
+      lds_sync();
+#ifdef AT_DEV_SWITCHES
+      RT_STAT(5, wall_clock64() - tick0);      // 100 MHz ticks inside the scan path
+#endif
+    }
+    bool try_fast = !fast_done && p.ranks != nullptr && max_val > abstol;
     if (try_fast) {
       // Pervasive ties: a held frame, a hop-periodic tone or a test signal makes row f equal row f-1, every
       // pop then lands in a tie group whose block visits its tied partner and the frame is redone on the heap anyway --
@@ -1778,6 +1988,9 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     lds_sync();
+#ifdef AT_DEV_SWITCHES
+    RT_STAT(6, wall_clock64() - tickf0);     // 100 MHz ticks per frame, everything included
+#endif
   }
 }
 
@@ -1986,6 +2199,7 @@ static int pghi_realtime_impl(const float* mag_hist, const float* mag, const flo
   p.S = S; p.n = n; p.F = F; p.n_fft = n_fft; p.hop = hop; p.gamma = gamma; p.tol = tol; p.eps = eps;
   p.ranks = nullptr;
   p.rank_stride = rt_rank_stride_u16(F);
+  p.scan_path = 0;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pghi_grad_rt_kernel, dim3(grid1d((long long)S * per)), dim3(256), 0, s, p);
   const size_t lds = sizeof(float) * (7 * (size_t)F + 1) + sizeof(HeapItem) * (4 * (size_t)F + 8);
@@ -1993,10 +2207,15 @@ static int pghi_realtime_impl(const float* mag_hist, const float* mag, const flo
   // cooperative heap kernel without the rank fast path
   const int pghi_kernel = variant(kVarPghiKernel);
   const bool serial_rt = pghi_kernel == 2;
+  p.scan_path = pghi_kernel == 0;            // 4: the rank fast path without the scan path in front of it
   // the fast path keeps 2F 16-byte records where the heap would be and 8F + 512 bytes of tables behind them
   const size_t lds_fast = sizeof(float) * (7 * (size_t)F + 4) + 16 * (2 * (size_t)F) + 8 * (size_t)F + 512 + 16;
+  // Default (variant 0): the scan path resolves a frame without a queue and declines only competing ties and islands of
+  // several unreached bins (dense noise: none in 8e4 frames; sparse frames that decline are cheap on the heap), so the
+  // rank pre-pass -- 84 us per call at 256 streams x 4 frames, more than the scan path's whole flood -- is not run:
+  // scan -> heap.  Variant 4 keeps round 4's chain rank bitmap -> heap (and its tests), variant 3 the heap alone.
   bool rank_path = false;
-  if (lds_fast <= 64 * 1024 && !serial_rt && pghi_kernel != 3 && 2 * F <= 2048 && F >= 8 && (long long)S * n < (1LL << 31)) {
+  if (pghi_kernel == 4 && lds_fast <= 64 * 1024 && 2 * F <= 2048 && F >= 8 && (long long)S * n < (1LL << 31)) {
     rank_path = true;
     // rank pre-pass: one workgroup per (stream, new frame) sorts the frame's 2F candidates
     uintptr_t rp = ((uintptr_t)(p.heap + (size_t)S * (4 * (size_t)F + 8)) + 15) & ~(uintptr_t)15;
@@ -2054,3 +2273,14 @@ int at_rt_update_buffers(const float* mag, const float* phase, int S, int n, int
 }
 
 }  // extern "C"
+
+#ifdef AT_DEV_SWITCHES
+extern "C" int at_dev_rt_stats(unsigned* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(at_hip::g_rt_stats), 8 * sizeof(unsigned)) != hipSuccess) return -5;
+  if (reset) {
+    unsigned z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(at_hip::g_rt_stats), z, sizeof(z)) != hipSuccess) return -5;
+  }
+  return 0;
+}
+#endif

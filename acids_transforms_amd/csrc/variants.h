@@ -18,7 +18,8 @@ enum {
   kVarSmallProjection = 2,  // 0: matrix-core form of the K <= 128 projection (the DCT behind MFCC); 1: row kernel
   kVarScanLayout = 3,       // 0: one block per clip for rows that are not whole 64-byte segments; 1: flattened columns
   kVarPghiKernel = 4,       // 0: cooperative heap kernels (+ rank fast path, realtime); 1: winner-bit offline kernel;
-                            // 2: single-lane kernels; 3: cooperative kernels, realtime without the rank fast path
+                            // 2: single-lane kernels; 3: cooperative kernels, realtime on the heap only; 4: realtime with the
+                            // rank fast path but without the wavefront-parallel scan path in front of it
   kVarIstftRuns = 5,        // 1: the n_fft-1024 inverse always as one long run per wave (no workgroup tiles with LDS hand-over)
   kVarCount = 6
 };

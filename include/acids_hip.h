@@ -51,7 +51,8 @@ const char *at_error_string(int code);
 #define AT_VARIANT_SMALL_PROJECTION 2  /* 1: row kernel instead of the matrix-core form of the K <= 128 projection */
 #define AT_VARIANT_SCAN_LAYOUT 3       /* 1: flattened columns instead of one block per clip in the phase scans */
 #define AT_VARIANT_PGHI_KERNEL 4       /* 1: winner-bit offline heap kernel; 2: single-lane heap kernels; 3: realtime
-                                        * flood on the heap even where the rank fast path applies */
+                                        * flood on the heap only; 4: realtime flood on the rank bitmap / heap, without the
+                                        * wavefront-parallel scan path (round 5) that is tried first by default */
 #define AT_VARIANT_ISTFT_RUNS 5        /* 1: n_fft-1024 inverse as one long run per wave even for full batches (no workgroup
                                         * tiles with the overlap state handed over through LDS) */
 int at_set_variant(int which, int value);

@@ -353,7 +353,8 @@ def test_direct_pghi_calls_use_the_reference_defaults(dev):
                                             (2048, 512, 2, 2), (64, 16, 3, 3)])
 def test_realtime_rank_fast_path_equals_the_heap_kernels(dev, n_fft, hop, S, n):
     """Round 4: where no two candidate magnitudes of a frame are equal, the realtime flood hands its entries out through a
-    bitmap over their ranks (sorted by a pre-pass) instead of the heap.  Same pop order, same float operations: the
+    bitmap over their ranks (sorted by a pre-pass) instead of the heap (since round 5: variant 4; the default tries the
+    queue-free scan path first and goes to the heap when that declines -- all four routes must agree).  Same pop order, same float operations: the
     phases must be the SAME BITS as the cooperative heap kernel's (variant 3) and the single-lane kernel's (variant 2), on
     noise, on sparse spectra (reseeds inside a frame, bins below the tolerance) and on input with exact ties -- quantised
     magnitudes, and a frame repeated exactly (every candidate of row f ties with row f-1) -- where the pre-pass reports
@@ -381,13 +382,92 @@ def test_realtime_rank_fast_path_equals_the_heap_kernels(dev, n_fft, hop, S, n):
             heap = ops.pghi_realtime(hist, mag, prev, noise, *args)
         with variant("pghi_kernel", 2):
             serial = ops.pghi_realtime(hist, mag, prev, noise, *args)
+        with variant("pghi_kernel", 4):                     # round 5: the rank path without the scan path in front of it
+            ranked = ops.pghi_realtime(hist, mag, prev, noise, *args)
         assert torch.equal(got, heap), (kind, float((got - heap).abs().max()))
         assert torch.equal(got, serial), (kind, float((got - serial).abs().max()))
+        assert torch.equal(got, ranked), (kind, float((got - ranked).abs().max()))
         assert bool(torch.isfinite(got).all())
         if kind in ("noise", "sparse"):          # and the checker itself: the C restatement of dgt.py:330-466
             ref = O.pghi_realtime(hist.cpu().numpy(), mag.cpu().numpy(), prev.cpu().numpy(), noise.cpu().numpy(), n_fft, hop,
                                   tol=float(rt.tolerance), gamma=float(rt.gamma), eps=float(rt.eps))["phase"]
             assert np.all(np.abs(cpu(got) - ref) <= phase_tol(ref, base=2e-3, ulps=16)), kind
+
+
+def test_realtime_scan_path_edge_cases(dev):
+    """Round 5: by default a realtime frame is resolved WITHOUT a queue -- two directional scans of clamp functions give
+    every bin the level at which it is reached and by whom, the phases follow the parent chains (`rt_scan_frame`,
+    pghi.hip) -- and only competing ties / islands of several unreached bins go to the heap.  The cases the derivation has
+    to get right, each against the cooperative heap kernel (variant 3) bit for bit: the frame maximum (the reference's
+    UNMARKED seed, dgt.py:427) at bin 0, 1, F-2, F-1, under a larger / smaller / dead source, between dead neighbours;
+    bin 0 under a dead source (never reached from above, :453: a one-bin reseed); onsets (row f live where row f-1 is
+    silent: islands of several bins -> declined); silence; one live bin; exact ties next to the maximum; plus random
+    sparsity patterns of both rows."""
+    n_fft, hop, F = 1024, 256, 513
+    g = torch.Generator().manual_seed(555)
+    rt = A.RealtimeDGT(n_fft=n_fft, hop_length=hop, batch_size=[1]).to(dev)
+    args = (float(rt.gamma), n_fft, hop, float(rt.tolerance), float(rt.eps))
+
+    def ray(*shape):
+        return (torch.randn(*shape, generator=g) ** 2 + torch.randn(*shape, generator=g) ** 2).sqrt() + 0.05
+
+    cases = []
+    for kmax in (0, 1, 2, F - 2, F - 1, 200):
+        for src in ("larger", "smaller", "dead"):
+            for nb in ("live", "dead", "left_dead", "right_dead"):
+                m = ray(6, F)
+                m[2:] = m[2:].clamp(max=3.0)
+                for f in range(2, 6):
+                    m[f, kmax] = 5.0 + 0.1 * f                                  # the frame maximum of rows 2..5
+                    m[f - 1, kmax] = {"larger": 9.0 + f, "smaller": 1.0, "dead": 0.0}[src] if f - 1 < 2 else m[f - 1, kmax]
+                    if nb in ("dead", "left_dead") and kmax - 1 >= 0:
+                        m[f, kmax - 1] = 0.0
+                    if nb in ("dead", "right_dead") and kmax + 1 < F:
+                        m[f, kmax + 1] = 0.0
+                m[1, kmax] = {"larger": 9.0, "smaller": 1.0, "dead": 0.0}[src]
+                cases.append(m)
+    m = ray(6, F)
+    m[0:2, 0] = 0.0
+    cases.append(m)                                                             # bin 0 under a dead source
+    m = ray(6, F) * (torch.rand(6, F, generator=g) < 0.5)
+    cases.append(m)                                                             # half the bins dead in every row
+    m = ray(6, F)
+    m[:3] = 0.0
+    cases.append(m)                                                             # onset: silence, then noise
+    m = ray(6, F)
+    m[3:] = 0.0
+    cases.append(m)                                                             # offset: noise, then silence
+    m = torch.zeros(6, F)
+    m[:, 77] = 1.0
+    cases.append(m)                                                             # one live bin
+    m = ray(6, F)
+    m[2:, 300] = 7.0
+    m[2:, 301] = 7.0
+    cases.append(m)                                                             # the maximum twice, side by side
+    m = ray(6, F)
+    m[2:, 300] = 7.0
+    m[1:5, 302] = 7.0
+    cases.append(m)                                                             # a source tied with the seed two bins away
+    for _ in range(40):
+        dens0, dens1 = float(torch.rand(1, generator=g)), float(torch.rand(1, generator=g))
+        m = ray(6, F)
+        m[0::2] = m[0::2] * (torch.rand(3, F, generator=g) < dens0)
+        m[1::2] = m[1::2] * (torch.rand(3, F, generator=g) < dens1)
+        cases.append(m)
+    spec = torch.stack(cases)                                                   # (cases, 6, F): every case a stream
+    S = spec.shape[0]
+    hist, mag = spec[:, :2].contiguous().to(dev), spec[:, 2:].contiguous().to(dev)
+    prev = (torch.rand(S, F, generator=g) * 6.28).to(dev)
+    noise = torch.randn(S, 4, F, generator=g).to(dev)
+    got = ops.pghi_realtime(hist, mag, prev, noise, *args)
+    with variant("pghi_kernel", 3):
+        heap = ops.pghi_realtime(hist, mag, prev, noise, *args)
+    with variant("pghi_kernel", 4):
+        ranked = ops.pghi_realtime(hist, mag, prev, noise, *args)
+    bad = (got != heap).flatten(1).any(1).nonzero().flatten().tolist()
+    assert not bad, ("streams that differ from the heap kernel", bad[:10])
+    assert torch.equal(ranked, heap)
+    assert bool(torch.isfinite(got).all())
 
 
 def test_realtime_rank_fast_path_with_injected_ties(dev):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Realtime PGHI: the rank fast path against the cooperative heap kernel (at_set_variant pghi_kernel = 3) on spectra with
+"""Realtime PGHI: the scan path (default, round 5) AND the rank fast path (at_set_variant pghi_kernel = 4) against the
+cooperative heap kernel (pghi_kernel = 3) on spectra with
 INJECTED ties -- a handful of magnitudes per stream copied to other bins of the same or the neighbouring frame, at random
 distances (far apart: the pops commute and the frame stays on the fast path; one or two bins apart, or onto the frame
 maximum: the pre-pass must report them and the frame must take the heap).  Phases must be the same bits."""
@@ -45,11 +46,15 @@ for case in range(n_cases):
     noise = torch.from_numpy(rng.randn(S, n, F).astype(np.float32)).to(dev)
     args = (float(rt.gamma), n_fft, hop, float(rt.tolerance), float(rt.eps))
     got = ops.pghi_realtime(hist, mag, prev, noise, *args)
+    with variant("pghi_kernel", 4):
+        ranked = ops.pghi_realtime(hist, mag, prev, noise, *args)
     with variant("pghi_kernel", 3):
         ref = ops.pghi_realtime(hist, mag, prev, noise, *args)
-    if not torch.equal(got, ref):
-        bad = (got != ref).nonzero()
-        print("MISMATCH case %d n_fft %d S %d n %d kind %s: %d bins, first %s" % (case, n_fft, S, n, kind, len(bad), bad[0].tolist()))
-        sys.exit(1)
+    for name, out in (("scan", got), ("rank", ranked)):
+        if not torch.equal(out, ref):
+            bad = (out != ref).nonzero()
+            print("MISMATCH (%s path) case %d n_fft %d S %d n %d kind %s: %d bins, first %s" % (
+                name, case, n_fft, S, n, kind, len(bad), bad[0].tolist()))
+            sys.exit(1)
     frames += S * n
-print("%d cases ok (%d stream-frames), fast path == heap kernel bit for bit" % (n_cases, frames))
+print("%d cases ok (%d stream-frames), scan path == rank fast path == heap kernel bit for bit" % (n_cases, frames))

@@ -10,3 +10,8 @@ sess = StreamingDGTSession(S, C, 1024, 256, 44100, device=dev, use_graph=False)
 for _ in range(10):
     sess.step(chunk)
 torch.cuda.synchronize()
+# 16 different chunks in turn (the same chunk again and again ties every candidate of the flood with its predecessor)
+chunks = [torch.randn(S, C, device=dev) * 0.1 for _ in range(16)]
+for i in range(40):
+    sess.step(chunks[i % 16])
+torch.cuda.synchronize()

@@ -11,7 +11,7 @@ from acids_transforms_amd.streaming import StreamingDGTSession
 dev = torch.device("cuda:0")
 S = int(os.environ.get("STREAMS", "256"))
 for C in (256, 1024, 4096):
-    for kern in (0, 3, 0, 3):
+    for kern in (0, 4, 3, 0, 4):
         with variant("pghi_kernel", kern):
             # a different chunk every step (32 of them in turn): fed the SAME hop-sized chunk again and again, every frame of
             # a stream is the frame before it, all candidates of the flood tie, and the heap path is what gets timed
