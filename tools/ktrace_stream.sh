@@ -2,7 +2,7 @@
 # kernel mix of the streaming step (eager) under rocprofv3
 REPO=$(pwd); OUT=$REPO/gpurun_out/r05r_stream_trace; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-STREAMS=256 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $REPO/tools/stream_prof.py > $OUT/log.txt 2>&1
+STREAMS=256 CHUNK=${CHUNK:-1024} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $REPO/tools/stream_prof.py > $OUT/log.txt 2>&1
 cd $REPO
 python3 - <<PY
 import csv, glob, collections

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from acids_transforms_amd.streaming import StreamingDGTSession
 dev = torch.device("cuda:0")
-S, C = int(os.environ.get("STREAMS", "256")), 1024
+S, C = int(os.environ.get("STREAMS", "256")), int(os.environ.get("CHUNK", "1024"))
 chunk = torch.randn(S, C, device=dev) * 0.1
 sess = StreamingDGTSession(S, C, 1024, 256, 44100, device=dev, use_graph=False)
 for _ in range(10):
