@@ -1661,12 +1661,15 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
   float abstol = p.tol * smax;  // :400
   if (abstol < p.eps) abstol = p.eps;
 
-  for (int k = lane; k < F; k += 64) {  // :402-403 rows 0 and 1 of the phase array
-    phase[k] = 0.0f;
-    phase[F + k] = p.prev_phase[(long long)s * F + k];
+  // :402-403 row 1 of the phase array is the previous call's last row.  The phase row of the frame before and its time
+  // gradient stay in LDS from frame to frame (round 5): the work array in global memory was written, fenced at agent
+  // scope and read back by the same wave every frame -- a third of the scan path's time per frame.
+  for (int k = lane; k < F; k += 64) {
+    ph1[k] = p.prev_phase[(long long)s * F + k];
+    tg1[k] = 0.0f;                       // :408-410 two-row front padding: the gradient row "before" frame 2
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+  (void)phase;
+  lds_sync();
 
   for (int f = 2; f < R; ++f) {  // :413
 #ifdef AT_DEV_SWITCHES
@@ -1674,18 +1677,41 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
 #endif
     float max_val = -1.0f;
     long long max_k = F;
-    for (int k = lane; k < F; k += 64) {
-      const float v = spec[(long long)f * F + k];
-      srow[k] = v;
-      hrow[k] = spec[(long long)(f - 1) * F + k];
-      ph0[k] = phase[(long long)(f - 1) * F + k];
-      ph1[k] = (v > abstol) ? 0.0f : p.noise[(long long)s * p.n * F + (long long)(f - 2) * F + k];  // :404-405
-      tg0[k] = (f - 1 >= 2) ? tgw[(long long)(f - 3) * F + k] : 0.0f;  // :408-410 two-row front padding
-      tg1[k] = tgw[(long long)(f - 2) * F + k];
-      fg1[k] = fgw[(long long)(f - 2) * F + k];
-      if (v > max_val) {
-        max_val = v;
-        max_k = k;
+    for (int k = lane; k < F; k += 64) {   // rows f-1 of the phase and of tgradw: last frame's ph1 / tg1
+      ph0[k] = ph1[k];
+      tg0[k] = tg1[k];
+    }
+    lds_sync();
+    // four strides of 64 bins per trip, all 28 loads requested before the first is used: one wave per SIMD hides nothing,
+    // and a trip per 64 bins was nine dependent round trips to global memory per frame (11 us of the scan path's 27)
+    for (int kb = lane; kb < F; kb += 256) {
+      float v_[4], h_[4], nz_[4], t1_[4], g1_[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = kb + 64 * u;
+        const bool in = k < F;
+        const long long kk = in ? k : 0;
+        v_[u] = spec[(long long)f * F + kk];
+        h_[u] = spec[(long long)(f - 1) * F + kk];
+        nz_[u] = p.noise[(long long)s * p.n * F + (long long)(f - 2) * F + kk];
+        t1_[u] = tgw[(long long)(f - 2) * F + kk];
+        g1_[u] = fgw[(long long)(f - 2) * F + kk];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = kb + 64 * u;
+        if (k < F) {
+          const float v = v_[u];
+          srow[k] = v;
+          hrow[k] = h_[u];
+          ph1[k] = (v > abstol) ? 0.0f : nz_[u];  // :404-405
+          tg1[k] = t1_[u];
+          fg1[k] = g1_[u];
+          if (v > max_val) {
+            max_val = v;
+            max_k = k;
+          }
+        }
       }
     }
     wave_argmax(max_val, max_k);
@@ -1980,13 +2006,7 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
       }
     }
     lds_sync();
-    for (int k = lane; k < F; k += 64) {
-      const float v = ph1[k];
-      phase[(long long)f * F + k] = v;
-      p.phase_out[(long long)s * p.n * F + (long long)(f - 2) * F + k] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    for (int k = lane; k < F; k += 64) p.phase_out[(long long)s * p.n * F + (long long)(f - 2) * F + k] = ph1[k];
     lds_sync();
 #ifdef AT_DEV_SWITCHES
     RT_STAT(6, wall_clock64() - tickf0);     // 100 MHz ticks per frame, everything included
