@@ -1402,171 +1402,206 @@ __device__ unsigned g_rt_stats[8];     // dev builds: frames, scan successes, re
 // the visited one if the bin's own source is larger than b_kmax, the initial one otherwise (the bin is then visited
 // later, possibly by one of S's own children).
 //
-// Declined (returns false, nothing written; the caller runs the rank / heap flood): a live bin nothing reaches (the
-// reference reseeds, :461-465 -- sparse spectra), or two candidates for a bin's parent with EQUAL levels (tied
-// magnitudes that actually compete: only the heap knows their order).  Ties that never meet are harmless.
+// Declined (returns false, nothing written; the caller runs the rank / heap flood): islands of several live bins that
+// nothing reaches (the reference reseeds, :461-465 -- onsets in sparse spectra; a one-bin island just keeps its initial
+// phase), two candidates for a bin's parent with EQUAL levels (tied magnitudes that actually compete: only the heap
+// knows their order), the seed's bin visited at exactly the seed's level.  Ties that never meet are harmless.
+//
+// Lane l owns the CONTIGUOUS bins [l C, (l + 1) C), C = ceil(F / 64) <= CM (compile-time: every loop below is unrolled
+// and predicated): the row is read from LDS once, the four scan walks, the parent choice and the rounds along the parent
+// chains run on registers, chunk boundaries cross lanes by shuffles.  (A first version kept the arrivals and the chains
+// in LDS: 15.6 us per frame against 10.5.)
+template <int CM>
 __device__ bool rt_scan_frame(const int F, const int lane, const float abstol, const int kmax, const float* srow,
-                              const float* hrow, const float* ph0, float* ph1, const float* tg0, const float* tg1,
-                              const float* fg1, float* scratch) {
+                                   const float* hrow, const float* ph0, float* ph1, const float* tg0, const float* tg1,
+                                   const float* fg1, float* scratch) {
   const float NEG = -__builtin_inff(), POS = __builtin_inff();
-  float* xl = scratch;                                   // level arriving at bin k from the left
-  float* yr = scratch + F;                               // ... from the right
-  int* par = reinterpret_cast<int*>(scratch + 2 * F);    // 0 dead / 1 source / 2 left / 3 right; bit 4: phase final
+  int* par = reinterpret_cast<int*>(scratch);             // parent codes, for the island test across lane boundaries
   auto sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  const int C = (F + 63) >> 6;                           // contiguous bins per lane
+  auto apply = [](float lo, float hi, float v) { return fminf(hi, fmaxf(lo, v)); };
+  const int C = (F + 63) >> 6;
   const int k0 = lane * C < F ? lane * C : F;
   const int k1 = k0 + C < F ? k0 + C : F;
-  // the clamp of bin k: level at which (f, k) pops, given the best level arriving from behind
-  auto clamp_of = [&](int k, float& lo, float& hi) {
-    const float b = srow[k];
-    if (k == kmax) {                       // S pops at its own key
-      lo = hi = b;
-    } else if (!(b > abstol)) {            // dead: never visited, never pops
-      lo = hi = NEG;
+  const int nb = k1 - k0;                                // bins this lane owns (0 .. C)
+  float b_[CM], c_[CM], lo_[CM], hi_[CM], fg_[CM];
+#pragma unroll
+  for (int i = 0; i < CM; ++i) {
+    const bool in = i < nb;
+    const int k = in ? k0 + i : 0;
+    const float b = srow[k], a = hrow[k];
+    fg_[i] = fg1[k];
+    b_[i] = b;
+    c_[i] = a > abstol ? a : NEG;
+    if (!in) {                                           // identity: the chunk ends before CM bins
+      lo_[i] = NEG;
+      hi_[i] = POS;
+      b_[i] = NEG;
+    } else if (k == kmax) {
+      lo_[i] = hi_[i] = b;
+    } else if (!(b > abstol)) {
+      lo_[i] = hi_[i] = NEG;
     } else {
-      const float a = hrow[k];
-      hi = b;
-      lo = a > abstol ? fminf(a, b) : NEG;
+      hi_[i] = b;
+      lo_[i] = fminf(c_[i], b);
     }
-  };
-  auto apply = [](float lo, float hi, float v) { return fminf(hi, fmaxf(lo, v)); };
-
-  // ---- left-to-right: the lane's chunk as one clamp, inclusive scan over the lanes, then the per-bin arrivals
-  float lo = NEG, hi = POS;
-  for (int k = k0; k < k1; ++k) {
-    float l, h;
-    clamp_of(k, l, h);
-    lo = apply(l, h, lo);
-    hi = apply(l, h, hi);
   }
+  float x_[CM], y_[CM];
+  {
+    float lo = NEG, hi = POS;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float plo = __shfl_up(lo, d, 64), phi = __shfl_up(hi, d, 64);
-    if (lane >= d) {
-      const float nlo = apply(lo, hi, plo), nhi = apply(lo, hi, phi);
-      lo = nlo;
-      hi = nhi;
+    for (int i = 0; i < CM; ++i) {
+      lo = apply(lo_[i], hi_[i], lo);
+      hi = apply(lo_[i], hi_[i], hi);
     }
-  }
-  float arr = __shfl_up(lo, 1, 64);        // everything left of this lane applied to "nothing arrives" = its lower bound
-  if (lane == 0) arr = NEG;
-  for (int k = k0; k < k1; ++k) {
-    xl[k] = arr;
-    float l, h;
-    clamp_of(k, l, h);
-    arr = apply(l, h, arr);
-  }
-  // ---- right-to-left
-  lo = NEG;
-  hi = POS;
-  for (int k = k1 - 1; k >= k0; --k) {
-    float l, h;
-    clamp_of(k, l, h);
-    lo = apply(l, h, lo);
-    hi = apply(l, h, hi);
-  }
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float plo = __shfl_down(lo, d, 64), phi = __shfl_down(hi, d, 64);
-    if (lane + d < 64) {
-      const float nlo = apply(lo, hi, plo), nhi = apply(lo, hi, phi);
-      lo = nlo;
-      hi = nhi;
+    for (int d = 1; d < 64; d <<= 1) {
+      const float plo = __shfl_up(lo, d, 64), phi = __shfl_up(hi, d, 64);
+      if (lane >= d) {
+        const float nlo = apply(lo, hi, plo), nhi = apply(lo, hi, phi);
+        lo = nlo;
+        hi = nhi;
+      }
+    }
+    float arr = __shfl_up(lo, 1, 64);
+    if (lane == 0) arr = NEG;
+#pragma unroll
+    for (int i = 0; i < CM; ++i) {
+      x_[i] = arr;
+      arr = apply(lo_[i], hi_[i], arr);
     }
   }
-  arr = __shfl_down(lo, 1, 64);
-  if (lane == 63) arr = NEG;
-  for (int k = k1 - 1; k >= k0; --k) {
-    yr[k] = k >= 1 ? arr : NEG;            // bin 0 is never reached downward
-    float l, h;
-    clamp_of(k, l, h);
-    arr = apply(l, h, arr);
+  {
+    float lo = NEG, hi = POS;
+#pragma unroll
+    for (int i = CM - 1; i >= 0; --i) {
+      lo = apply(lo_[i], hi_[i], lo);
+      hi = apply(lo_[i], hi_[i], hi);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float plo = __shfl_down(lo, d, 64), phi = __shfl_down(hi, d, 64);
+      if (lane + d < 64) {
+        const float nlo = apply(lo, hi, plo), nhi = apply(lo, hi, phi);
+        lo = nlo;
+        hi = nhi;
+      }
+    }
+    float arr = __shfl_down(lo, 1, 64);
+    if (lane == 63) arr = NEG;
+#pragma unroll
+    for (int i = CM - 1; i >= 0; --i) {
+      y_[i] = (k0 + i >= 1) ? arr : NEG;                 // bin 0 is never reached downward
+      arr = apply(lo_[i], hi_[i], arr);
+    }
   }
-  sync();
-
-  // ---- parents.  The seed's own bin sees its neighbours as S's children (S reaches them whatever else does).
+  // ---- parents
   const float bmax = srow[kmax];
   const float amax = hrow[kmax];
   const float cmax = amax > abstol ? amax : NEG;
+  const float b_below = kmax - 1 >= 1 ? srow[kmax - 1] : 0.0f;          // the seed's neighbours, as S's children
+  const float b_above = (kmax >= 1 && kmax + 1 < F) ? srow[kmax + 1] : 0.0f;
   bool bad = false, bad_reseed = false;
-  for (int k = k0; k < k1; ++k) {
-    const float b = srow[k];
+  int code_[CM];
+#pragma unroll
+  for (int i = 0; i < CM; ++i) {
+    const int k = k0 + i;
     int code = 0;
-    if (b > abstol) {
-      const float a = hrow[k];
-      const float c = a > abstol ? a : NEG;
-      float x = xl[k], y = yr[k];
+    if (i < nb && b_[i] > abstol) {
+      const float c = c_[i];
+      float x = x_[i], y = y_[i];
       if (k == kmax) {
-        if (k - 1 >= 1 && srow[k - 1] > abstol) x = srow[k - 1];
-        if (k >= 1 && k + 1 < F && srow[k + 1] > abstol) y = srow[k + 1];
+        if (b_below > abstol) x = b_below;
+        if (b_above > abstol) y = b_above;
       }
       const float m = fmaxf(c, fmaxf(x, y));
-      if ((int)(c == m) + (int)(x == m) + (int)(y == m) > 1 && m != NEG) bad = true;  // competing tie
-      // the seed's bin visited at the very level S pops at (its source or a neighbour ties with the frame maximum): which
-      // phase S hands on is then the heap's to say
+      if ((int)(c == m) + (int)(x == m) + (int)(y == m) > 1 && m != NEG) bad = true;
       if (k == kmax && m == bmax) bad = true;
       code = m == NEG ? 4 : (c == m ? 1 : (x == m ? 2 : 3));
     }
-    par[k] = code;
+    code_[i] = code;
+    if (i < nb) par[k] = code;
   }
-  // Live bins nothing reaches (code 4) are what the reference reseeds (:461-465), largest first.  A reseeded bin keeps
-  // its initial phase and floods its own island of unreached live neighbours; an island of ONE bin -- bin 0 under a dead
-  // source is the usual case: nothing reaches bin 0 from above (:453) -- floods nothing and meets nobody, whatever the
-  // order of the reseeds.  Larger islands are left to the queue.
   sync();
-  for (int k = k0; k < k1; ++k)
-    if (par[k] == 4 && ((k >= 1 && par[k - 1] == 4) || (k + 1 < F && par[k + 1] == 4))) bad = bad_reseed = true;
+#pragma unroll
+  for (int i = 0; i < CM; ++i) {
+    const int k = k0 + i;
+    if (i < nb && code_[i] == 4 && ((k >= 1 && par[k - 1] == 4) || (k + 1 < F && par[k + 1] == 4))) bad = bad_reseed = true;
+  }
   RT_STAT(0, 1);
   if (__ballot(bad) != 0) {
     RT_STAT(__ballot(bad_reseed) != 0 ? 3 : 4, 1);
     return false;
   }
   const float phi_s = cmax > bmax ? ph0[kmax] + 0.5f * (tg0[kmax] + tg1[kmax]) : ph1[kmax];
-  sync();
-
-  // ---- phases along the parent pointers: a left-to-right pass settles sources and chains that lean left, a right-to-
-  // left pass the ones that lean right; chains that cross a lane boundary take another round
+  // ---- phases: sources at once, then the chains; a bin adds its own step onto its parent's FINAL phase, nothing else
+  float val_[CM];
+  bool done_[CM];
+#pragma unroll
+  for (int i = 0; i < CM; ++i) {
+    const int k = i < nb ? k0 + i : 0;
+    done_[i] = false;
+    val_[i] = 0.0f;
+    if (code_[i] == 1) {
+      val_[i] = ph0[k] + 0.5f * (tg0[k] + tg1[k]);
+      done_[i] = true;
+    }
+  }
+  const float fg_left = fg1[k0 >= 1 ? k0 - 1 : 0];       // the neighbours' frequency gradients across the chunk boundaries
+  const float fg_right = fg1[k1 < F ? k1 : F - 1];
   for (int round = 0; round <= 64; ++round) {
+    // what the lane to the left / right holds at the boundary: its last / first bin
+    float last_val = 0.0f, first_val = val_[0];
+    bool last_done = false, first_done = done_[0];
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+      if (i == nb - 1) {
+        last_val = val_[i];
+        last_done = done_[i];
+      }
+    const float lv = __shfl_up(last_val, 1, 64), rv = __shfl_down(first_val, 1, 64);
+    const bool ld = __shfl_up((int)last_done, 1, 64) != 0 && lane >= 1;
+    const bool rd = __shfl_down((int)first_done, 1, 64) != 0 && lane < 63;
     bool pending = false;
-    for (int k = k0; k < k1; ++k) {
-      const int code = par[k];
-      if (code == 1) {
-        ph1[k] = ph0[k] + 0.5f * (tg0[k] + tg1[k]);
-        par[k] = 1 | 16;
-      } else if (code == 2) {
-        const int j = k - 1;
-        const bool ready = j == kmax || (par[j] & 16) != 0;
+#pragma unroll
+    for (int i = 0; i < CM; ++i) {
+      if (code_[i] == 2 && !done_[i]) {
+        const int j = k0 + i - 1;
+        const bool ready = j == kmax || (i == 0 ? ld : done_[i > 0 ? i - 1 : 0]);
         if (ready) {
-          const float pp = j == kmax ? phi_s : ph1[j];
-          ph1[k] = pp + 0.5f * (fg1[j] + fg1[k]);
-          par[k] = 2 | 16;
+          const float pp = j == kmax ? phi_s : (i == 0 ? lv : val_[i > 0 ? i - 1 : 0]);
+          val_[i] = pp + 0.5f * ((i == 0 ? fg_left : fg_[i > 0 ? i - 1 : 0]) + fg_[i]);
+          done_[i] = true;
         } else {
           pending = true;
         }
       }
     }
-    sync();
-    for (int k = k1 - 1; k >= k0; --k) {
-      if (par[k] == 3) {
-        const int j = k + 1;
-        const bool ready = j == kmax || (par[j] & 16) != 0;
+#pragma unroll
+    for (int i = CM - 1; i >= 0; --i) {
+      if (code_[i] == 3 && !done_[i]) {
+        const int j = k0 + i + 1;
+        const bool at_end = i == nb - 1;                 // the parent is the right-hand lane's first bin
+        const bool ready = j == kmax || (at_end ? rd : done_[i + 1 < CM ? i + 1 : CM - 1]);
         if (ready) {
-          const float pp = j == kmax ? phi_s : ph1[j];
-          ph1[k] = pp - 0.5f * (fg1[j] + fg1[k]);
-          par[k] = 3 | 16;
+          const float pp = j == kmax ? phi_s : (at_end ? rv : val_[i + 1 < CM ? i + 1 : CM - 1]);
+          val_[i] = pp - 0.5f * ((at_end ? fg_right : fg_[i + 1 < CM ? i + 1 : CM - 1]) + fg_[i]);
+          done_[i] = true;
         } else {
           pending = true;
         }
       }
     }
-    sync();
     RT_STAT(2, 1);
     if (__ballot(pending) == 0) break;
   }
+#pragma unroll
+  for (int i = 0; i < CM; ++i)
+    if (i < nb && code_[i] >= 1 && code_[i] <= 3) ph1[k0 + i] = val_[i];
+  sync();
   RT_STAT(1, 1);
   return true;
 }
@@ -1733,7 +1768,11 @@ __global__ __launch_bounds__(256) void pghi_hgi_rt_coop_kernel(RtParams p) {
 #ifdef AT_DEV_SWITCHES
       const unsigned long long tick0 = wall_clock64();
 #endif
-      fast_done = rt_scan_frame(F, lane, abstol, uni((int)max_k), srow, hrow, ph0, ph1, tg0, tg1, fg1, fg1 + F + (F & 1));
+      float* scan_scratch = fg1 + F + (F & 1);            // where the heap would be
+      const int kmx = uni((int)max_k);
+      if (F <= 64 * 9) fast_done = rt_scan_frame<9>(F, lane, abstol, kmx, srow, hrow, ph0, ph1, tg0, tg1, fg1, scan_scratch);
+      else if (F <= 64 * 17) fast_done = rt_scan_frame<17>(F, lane, abstol, kmx, srow, hrow, ph0, ph1, tg0, tg1, fg1, scan_scratch);
+      // (rows of more than 1088 bins do not fit this kernel's LDS budget anyway: n_fft 4096 runs on the global-memory kernels)
       lds_sync();
 #ifdef AT_DEV_SWITCHES
       RT_STAT(5, wall_clock64() - tick0);      // 100 MHz ticks inside the scan path
