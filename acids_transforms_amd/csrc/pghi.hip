@@ -1504,7 +1504,7 @@ __device__ bool rt_scan_frame(const int F, const int lane, const float abstol, c
   const float cmax = amax > abstol ? amax : NEG;
   const float b_below = kmax - 1 >= 1 ? srow[kmax - 1] : 0.0f;          // the seed's neighbours, as S's children
   const float b_above = (kmax >= 1 && kmax + 1 < F) ? srow[kmax + 1] : 0.0f;
-  bool bad = false, bad_reseed = false;
+  bool bad = false, bad_reseed = false, seed_tie = false;
   int code_[CM];
 #pragma unroll
   for (int i = 0; i < CM; ++i) {
@@ -1519,13 +1519,31 @@ __device__ bool rt_scan_frame(const int F, const int lane, const float abstol, c
       }
       const float m = fmaxf(c, fmaxf(x, y));
       if ((int)(c == m) + (int)(x == m) + (int)(y == m) > 1 && m != NEG) bad = true;
-      if (k == kmax && m == bmax) bad = true;
+      // the seed's bin visited at the very level S pops at (its source, or a neighbour, ties with the frame maximum):
+      // which phase S hands on is the heap's to say -- and matters only if S has a child (below)
+      if (k == kmax && m == bmax) seed_tie = true;
       code = m == NEG ? 4 : (c == m ? 1 : (x == m ? 2 : 3));
     }
     code_[i] = code;
     if (i < nb) par[k] = code;
   }
   sync();
+  // S's children: the bins next to the seed whose parent is the seed's side.  A held frame (row f equal to row f-1: a
+  // stationary signal, hop-periodic tones) ties every source with its own bin -- harmless everywhere (a source only ever
+  // visits its own bin) except at the seed, and there only if somebody takes S's phase.
+  // ... and only if some source is LARGER than the frame maximum: S is pushed first (:427) and an entry only rises past an
+  // equal key on a strict comparison (heapq.py:9-21), so with no larger source S is still the root when the flood starts and
+  // is its very first pop -- it hands on the initial phase, whatever ties with it (a held frame: the row maxima are equal).
+  if (__ballot(seed_tie) != 0 &&
+      ((kmax + 1 < F && par[kmax + 1] == 2) || (kmax - 1 >= 1 && par[kmax - 1] == 3))) {
+    float src_max = NEG;
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+      if (i < nb) src_max = fmaxf(src_max, c_[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) src_max = fmaxf(src_max, __shfl_xor(src_max, o, 64));
+    if (src_max > bmax) bad = true;
+  }
 #pragma unroll
   for (int i = 0; i < CM; ++i) {
     const int k = k0 + i;

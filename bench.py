@@ -1169,9 +1169,10 @@ def main():
                 cell["frames_per_s_" + tag] = S * (C // HOP) / dt
                 del sess
             if C == 256:
-                # the degenerate input kept visible: the SAME hop-sized chunk every step makes row f-1 == row f,
-                # every pop of the rank fast path lands in a tie group that visits its partner and the frame falls back to
-                # the heap -- it pays for the rank pre-pass AND the heap flood (held frames, hop-periodic tones do this)
+                # the degenerate input kept visible: the SAME hop-sized chunk every step makes row f-1 == row f --
+                # every source ties with its own bin (held frames, hop-periodic tones do this).  Round 4's rank bitmap fell
+                # back to the heap there (1.03 ms); the scan path takes it: a source only ever visits its own bin, and with
+                # no source larger than the frame maximum the unmarked seed is provably the flood's first pop
                 try:
                     sess = StreamingDGTSession(S, C, N_FFT, HOP, SR, device=dev, use_graph=True, mel_bands=N_MELS, mel_dtype="bf16")
                     for i in range(5):
