@@ -43,6 +43,11 @@ def test_a_failed_spot_check_fails_the_bench():
                 "achieved_vs_pattern_copy"):
         assert isinstance(roof.get(key), float), key
     assert line["hooks_armed"] == []
+    # the power side: either the device's hwmon files are readable and the line says what the step drew, or it says they are not
+    assert "power" in line, [k for k in line if k.endswith("_error")]
+    if line["power"]["available"]:
+        assert line["power"]["cap_watts"] > 0 and line["power"]["step"]["watts"] > 0 and line["power"]["step"]["sclk_mhz"] > 0
+        assert roof["power_cap_watts"] == line["power"]["cap_watts"] and roof["step_socket_watts"] > 0
     r, _ = _bench(SMALL + ["--no-extras"], {"ACIDS_BENCH_CORRUPT": "feat"})
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert r.returncode == 5, (r.returncode, r.stderr[-2000:])
