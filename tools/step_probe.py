@@ -370,6 +370,7 @@ def main():
         h.ek_run.argtypes = [I, I, I, V, V]
         h.pat_fwd_flags.argtypes = [V, V, V, I64, I, I, I, V]
         h.pat_inv_flags.argtypes = [V, V, I64, I, I, I, V]
+        h.pat_fwd513.argtypes = [V, V, V, I64, I, I, I, V]
         return h
 
     def powered_loop(fn, seconds=1.2, chunk=20, warm=10):
@@ -462,6 +463,29 @@ def main():
                 name, w["ms_per_launch"], w["frac_of_8TBps"], w.get("watts_mean", 0), w.get("sclk_mean", 0)), flush=True)
         res["phase"] = ph
         del Xs, Xo, inst, insto, Yp, Yi, x_odd
+
+    if "pat513" in sections:
+        # the reference-default chain STFT() + Magnitude(): spectrum + 513 features per frame (7180 B): what do these three
+        # streams cost with no arithmetic, feature rows written where they lie or as one stream of 1-KB blocks?
+        pl = pattern_lib()
+        Xb = torch.empty((B, T, 513), dtype=torch.complex64, device=dev)
+        fb = torch.empty((B * T * 513 + 1024,), dtype=torch.float32, device=dev)
+        xb = torch.empty((B * T * HOP + 1024,), dtype=torch.float32, device=dev).normal_()
+        mag513 = A.Magnitude(sr=SR, n_fft=N_FFT, mode="unipolar", contrast="log1p").to(dev)
+        mag513.scale_data(stft(x[:8]))
+        out = {}
+        for G in (173, 16):
+            for style, name in ((1, "rows"), (2, "1-KB blocks")):
+                w = powered_loop(lambda: pl.pat_fwd513(L.ptr(xb), L.ptr(Xb), L.ptr(fb), frames, G, 8, style, L.stream_ptr()))
+                out["G%d_%s" % (G, name)] = w
+                print("pat513  G=%-3d %-12s %.4f ms  %.3f of 8 TB/s  %5.0f W  sclk %4.0f" % (
+                    G, name, w["ms_per_launch"], frames * 7180 / (w["ms_per_launch"] * 1e-3) / 8e12, w.get("watts_mean", 0), w.get("sclk_mean", 0)), flush=True)
+        w = powered_loop(lambda: mag513.forward_fused(stft, x, return_spectrum=True))
+        print("pat513  product fused513     %.4f ms  %.3f of 8 TB/s  %5.0f W  sclk %4.0f" % (
+            w["ms_per_launch"], frames * 7180 / (w["ms_per_launch"] * 1e-3) / 8e12, w.get("watts_mean", 0), w.get("sclk_mean", 0)), flush=True)
+        out["product"] = w
+        res["pat513"] = out
+        del Xb, fb, xb
 
     if "memflavour" in sections:
         # Joules of the step's memory streams by store / load flavour (under a power cap the cheapest stream wins, not the

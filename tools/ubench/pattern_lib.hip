@@ -89,6 +89,55 @@ __device__ __forceinline__ void inv_run(const float2* __restrict__ in, float* __
   }
 }
 
+// forward + the reference's default 513 features per frame (2052-byte rows): STYLE 1 = every row written where it lies
+// (4-byte stores, lane l -> floats l + 64 j: what the generic epilogue's scatter amounts to at best), STYLE 2 = the feature
+// stream as whole 1-KB aligned blocks of 16 bytes per lane (what the packed epilogue writes)
+template <int STYLE>
+__global__ __launch_bounds__(512) void pat513_k(const float* __restrict__ x, float2* __restrict__ out, float* __restrict__ feat,
+                                                long long total, long long G) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const long long nruns = (total + G - 1) / G;
+  const long long w = (long long)blockIdx.x * wpb + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (w >= nruns) return;
+  const long long f0 = w * G;
+  long long f1 = f0 + G;
+  if (f1 > total) f1 = total;
+  vf2 raw[8];
+  {
+    const vf2* src = reinterpret_cast<const vf2*>(x + f0 * 256);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) raw[m + 2] = src[lane + 64 * m];
+  }
+  vf2* base = reinterpret_cast<vf2*>(out);
+  for (long long f = f0; f < f1; ++f) {
+    const vf2* src = reinterpret_cast<const vf2*>(x + f * 256 + 768);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) raw[m] = raw[m + 2];
+    raw[6] = src[lane];
+    raw[7] = src[lane + 64];
+    vf2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = raw[m] * (vf2){1.0001f, 0.9999f};
+    const long long b0 = (f * F) >> 6, b1 = ((f + 1) * F) >> 6;
+    int m = 0;
+    for (long long blk = b0; blk < b1; ++blk, ++m) __builtin_nontemporal_store(v[m & 7], base + blk * 64 + lane);
+    if (STYLE == 1) {
+      float* row = feat + f * F;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[lane + 64 * j] = v[j].x + v[j].y;
+      if (lane == 0) row[512] = v[0].x;
+    } else {
+      const long long q0 = (f * F) >> 8, q1 = ((f + 1) * F) >> 8;       // 256-float blocks
+      int j = 0;
+      for (long long blk = q0; blk < q1; ++blk, ++j) {
+        const vf4 q = {v[(2 * j) & 7].x, v[(2 * j) & 7].y, v[(2 * j + 1) & 7].x, v[(2 * j + 1) & 7].y};
+        *(reinterpret_cast<vf4*>(feat) + blk * 64 + lane) = q;
+      }
+    }
+  }
+}
+
 // KIND 0 forward, 1 forward + 128 features, 2 inverse; NT: non-temporal stores; ALT: 16-byte stores (forward) / plain loads (inverse)
 template <int KIND, int NT, int ALT>
 __global__ __launch_bounds__(512) void pat_k(const float* __restrict__ x, const float2* __restrict__ spec_in,
@@ -203,6 +252,19 @@ int pat_inv_flags(const void* spec, float* audio, long long total_frames, int G,
   if (blocks <= 0 || blocks >= (1LL << 31)) return -1;
   hipLaunchKernelGGL(pick<2>(flags), dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, (const float*)nullptr,
                      (const float2*)spec, (float2*)nullptr, audio, (float*)nullptr, total_frames, (long long)G);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// forward + 513 features per frame; style 1 rows, 2 aligned 1-KB blocks
+int pat_fwd513(const float* x, void* out, float* feat, long long total_frames, int G, int wpb, int style, void* stream) {
+  if (G < 1 || wpb < 1 || wpb > 8 || !feat) return -1;
+  const long long nruns = (total_frames + G - 1) / G;
+  const long long blocks = (nruns + wpb - 1) / wpb;
+  if (blocks <= 0 || blocks >= (1LL << 31)) return -1;
+  if (style == 1)
+    hipLaunchKernelGGL(pat513_k<1>, dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, x, (float2*)out, feat, total_frames, (long long)G);
+  else
+    hipLaunchKernelGGL(pat513_k<2>, dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, x, (float2*)out, feat, total_frames, (long long)G);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
